@@ -1,0 +1,170 @@
+"""
+``Comm``: the subset of the mpi4py communicator API that Hydra's GCR path uses
+(Get_rank / Get_size / barrier / Bcast / Reduce / Allreduce / Send / Recv / Create),
+on ``torch.distributed`` -- RCCL over xGMI when the process group is "nccl" (one
+process per MI355X), gloo for CPU-only runs and tests.
+
+Reference call sites replaced: ptsrc_sampler.py:86,132 (Reduce of Gram / RHS),
+sh_sampler.py:420,439,465,485 (Bcast + Reduce per CG iteration),
+linear_solver.py:48,121-124,222-230,313-367,473-508.
+
+Buffers may be numpy arrays (mpi4py style, modified in place) or torch tensors.  With the
+nccl backend host buffers are staged through the rank's GPU; with gloo GPU tensors are
+staged through the host.
+"""
+import os
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+SUM = "sum"
+MIN = "min"
+MAX = "max"
+_OPS = {"sum": dist.ReduceOp.SUM, "min": dist.ReduceOp.MIN, "max": dist.ReduceOp.MAX}
+
+
+def init_from_env(backend=None):
+    """Initialise the default process group from torchrun's environment
+    (RANK / WORLD_SIZE / LOCAL_RANK / MASTER_ADDR / MASTER_PORT) and bind this process to
+    its GPU.  Returns a world ``Comm`` (or None for a single-process run)."""
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if world <= 1:
+        return None
+    if backend is None:
+        backend = "nccl" if torch.cuda.is_available() else "gloo"
+    if torch.cuda.is_available():
+        torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
+    if not dist.is_initialized():
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend=backend)
+    return Comm()
+
+
+class Comm:
+    def __init__(self, group=None, ranks=None):
+        self.group = group                     # None = world
+        self.ranks = ranks                     # global ranks of the members (None = all)
+        self.backend = dist.get_backend(group) if (group is not None or dist.is_initialized()) \
+            else None
+
+    # ---- mpi4py-style queries
+    def Get_rank(self):
+        return dist.get_rank(self.group)
+
+    def Get_size(self):
+        return dist.get_world_size(self.group)
+
+    def barrier(self):
+        dist.barrier(group=self.group)
+
+    Barrier = barrier
+
+    def _global(self, group_rank):
+        return group_rank if self.ranks is None else self.ranks[group_rank]
+
+    def Create(self, ranks):
+        """Sub-communicator of the given (global) ranks; collective over the whole world, like
+        ``comm.Create(comm.group.Incl(ranks))`` (linear_solver.py:121-124).  Returns None on
+        ranks that are not members."""
+        ranks = [int(r) for r in ranks]
+        grp = dist.new_group(ranks=ranks)
+        if dist.get_rank() not in ranks:
+            return None
+        return Comm(group=grp, ranks=ranks)
+
+    # ---- staging
+    def _stage(self, buf):
+        """-> (tensor usable by the backend, write-back function)."""
+        if isinstance(buf, np.ndarray):
+            t = torch.from_numpy(buf)          # shares memory with the caller's array
+            if self.backend == "nccl":
+                d = t.cuda()
+                return d, lambda: t.copy_(d.cpu())
+            return t, lambda: None
+        if buf.is_cuda and self.backend != "nccl":
+            h = buf.cpu()
+            return h, lambda: buf.copy_(h)
+        if not buf.is_cuda and self.backend == "nccl":
+            d = buf.cuda()
+            return d, lambda: buf.copy_(d.cpu())
+        return buf, lambda: None
+
+    @staticmethod
+    def _as_real(t):
+        return torch.view_as_real(t) if t.is_complex() else t
+
+    # ---- in-place tensor collectives (used by hydra_amd itself)
+    def allreduce_(self, t, op="sum"):
+        s, back = self._stage(t)
+        dist.all_reduce(self._as_real(s), op=_OPS[op], group=self.group)
+        back()
+        return t
+
+    def reduce_(self, t, root=0, op="sum"):
+        s, back = self._stage(t)
+        dist.reduce(self._as_real(s), dst=self._global(root), op=_OPS[op], group=self.group)
+        if self.Get_rank() == root:
+            back()
+        return t
+
+    def bcast_(self, t, root=0):
+        s, back = self._stage(t)
+        dist.broadcast(self._as_real(s), src=self._global(root), group=self.group)
+        back()
+        return t
+
+    def allgather(self, t):
+        s, _ = self._stage(t)
+        parts = [torch.empty_like(s) for _ in range(self.Get_size())]
+        dist.all_gather(parts, s, group=self.group)
+        return [p.to(t.device) for p in parts] if isinstance(t, torch.Tensor) else parts
+
+    # ---- mpi4py-style buffer collectives
+    def Bcast(self, buf, root=0):
+        self.bcast_(buf, root)
+
+    def bcast(self, obj, root=0):
+        box = [obj]
+        dist.broadcast_object_list(box, src=self._global(root), group=self.group)
+        return box[0]
+
+    def Reduce(self, sendbuf, recvbuf, op=SUM, root=0):
+        tmp = np.array(sendbuf, copy=True) if isinstance(sendbuf, np.ndarray) else sendbuf.clone()
+        self.reduce_(tmp, root, op if isinstance(op, str) else "sum")
+        if self.Get_rank() == root:
+            if isinstance(recvbuf, np.ndarray):
+                recvbuf[...] = np.asarray(tmp).reshape(recvbuf.shape)
+            else:
+                recvbuf.copy_(tmp.reshape(recvbuf.shape))
+
+    def Allreduce(self, sendbuf, recvbuf, op=SUM):
+        tmp = np.array(sendbuf, copy=True) if isinstance(sendbuf, np.ndarray) else sendbuf.clone()
+        self.allreduce_(tmp, op if isinstance(op, str) else "sum")
+        if isinstance(recvbuf, np.ndarray):
+            recvbuf[...] = np.asarray(tmp).reshape(recvbuf.shape)
+        else:
+            recvbuf.copy_(tmp.reshape(recvbuf.shape))
+
+    def allreduce(self, value, op=SUM):
+        t = torch.tensor([float(value)], dtype=torch.float64)
+        self.allreduce_(t, op if isinstance(op, str) else "sum")
+        return t.item()
+
+    def Send(self, buf, dest):
+        s, _ = self._stage(np.ascontiguousarray(buf) if isinstance(buf, np.ndarray) else buf)
+        dist.send(self._as_real(s), dst=self._global(dest), group=self.group)
+
+    def Recv(self, buf, source):
+        s, back = self._stage(buf)
+        dist.recv(self._as_real(s), src=self._global(source), group=self.group)
+        back()
+
+    def Allgather(self, sendbuf, recvbuf):
+        parts = self.allgather(torch.from_numpy(np.ascontiguousarray(sendbuf))
+                               if isinstance(sendbuf, np.ndarray) else sendbuf)
+        flat = torch.cat([p.reshape(-1).cpu() for p in parts])
+        if isinstance(recvbuf, np.ndarray):
+            recvbuf[...] = flat.numpy().reshape(recvbuf.shape)
+        else:
+            recvbuf.copy_(flat.reshape(recvbuf.shape))

@@ -1,0 +1,108 @@
+"""
+Primary-beam objects accepted by ``hydra_amd.vis_simulator``.
+
+The reference hands pyuvdata beam objects to ``BeamInterface.compute_response``
+(hydra/vis_simulator.py:347-359, hydra/example.py:170-172).  Here a beam is any
+object with
+
+    compute_response(az_array=, za_array=, freq_array=, **kw) -> (1, 1, Nfreq, Npts) power
+
+Analytic beams defined in this module additionally carry ``hip_spec()``, which
+lets the HIP generator evaluate them in-kernel (no host round trip).  Any other
+object (e.g. a real pyuvdata beam, when that package is installed) is evaluated
+through its own ``compute_response`` on the host and uploaded as a value table
+(HYDRA_BEAM_VALUES).
+"""
+import numpy as np
+
+C_LIGHT = 299792458.0
+
+HYDRA_BEAM_GAUSS_DIAMETER = 0
+HYDRA_BEAM_GAUSS_SIGMA = 1
+HYDRA_BEAM_UNIFORM = 2
+HYDRA_BEAM_VALUES = 3
+HYDRA_BEAM_NPARAMS = 4
+
+
+class GaussianBeam:
+    """Gaussian power beam exp(-za^2/sigma^2); ``diameter`` (m) sets
+    sigma(nu) = arcsin(2.2150894 lambda / (pi D)) * 2 / 2.355 (pyuvdata's
+    ``GaussianBeam(diameter=...)``), or a fixed ``sigma`` (rad) with optional
+    power-law scaling from ``reference_frequency``."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, diameter=None, sigma=None, spectral_index=0.0,
+                 reference_frequency=None):
+        if (diameter is None) == (sigma is None):
+            raise ValueError("give exactly one of diameter, sigma")
+        self.diameter = diameter
+        self.sigma = sigma
+        self.spectral_index = spectral_index
+        self.reference_frequency = reference_frequency
+
+    def hip_spec(self):
+        if self.diameter is not None:
+            return HYDRA_BEAM_GAUSS_DIAMETER, [float(self.diameter), 0.0, 0.0, 0.0]
+        ref = 0.0 if self.reference_frequency is None else float(self.reference_frequency)
+        return HYDRA_BEAM_GAUSS_SIGMA, [float(self.sigma), ref, float(self.spectral_index), 0.0]
+
+    def get_sigmas(self, freq_array):
+        freq_array = np.asarray(freq_array, dtype=np.float64)
+        if self.diameter is not None:
+            return np.arcsin(2.2150894 * (C_LIGHT / freq_array) / (np.pi * self.diameter)) * 2 / 2.355
+        if self.reference_frequency is None:
+            return self.sigma * np.ones_like(freq_array)
+        return self.sigma * (freq_array / self.reference_frequency) ** self.spectral_index
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        za = np.asarray(za_array, dtype=np.float64)
+        sig = self.get_sigmas(np.atleast_1d(freq_array))
+        return np.exp(-(za[None, :] ** 2) / (sig[:, None] ** 2))[None, None]
+
+
+class UniformBeam:
+    """Unit response everywhere."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def hip_spec(self):
+        return HYDRA_BEAM_UNIFORM, [0.0, 0.0, 0.0, 0.0]
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        return np.ones((1, 1, np.atleast_1d(freq_array).size, np.asarray(za_array).size))
+
+
+def check_beams(beams, polarized=False):
+    """The validation of ``run_checks`` (vis_simulator.py:92-104)."""
+    if polarized:
+        raise NotImplementedError("polarized=True is not on the GCR hot path")
+    for b in beams:
+        bad_type = getattr(b, "beam_type", "power") != "power"
+        bad_npol = getattr(b, "Npols", 1) > 1
+        pol = getattr(b, "polarization_array", [-5])
+        if bad_type or bad_npol or pol[0] not in (-5, -6):
+            raise ValueError(
+                "beam type must be power and have only one pol (either xx or yy) if "
+                "polarized=False")
+
+
+def group_beams(beams):
+    """Deduplicate beam objects: returns (unique_beams, beam_idx per input beam).
+    Two analytic beams with equal ``hip_spec()`` are the same beam; other objects are
+    compared by identity.  (The reference evaluates one beam per antenna even when they
+    are identical, vis_simulator.py:248-253.)"""
+    uniq, keys, idx = [], [], []
+    for b in beams:
+        key = ("spec",) + tuple(map(repr, b.hip_spec())) if hasattr(b, "hip_spec") else ("id", id(b))
+        if key in keys:
+            idx.append(keys.index(key))
+        else:
+            keys.append(key)
+            uniq.append(b)
+            idx.append(len(uniq) - 1)
+    return uniq, np.asarray(idx, dtype=np.int32)

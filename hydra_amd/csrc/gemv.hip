@@ -1,0 +1,377 @@
+// Operator application kernels (HBM-bandwidth bound): R x, Re(R^H z) and the row-wise
+// GCR right-hand-side terms, for a materialised R (M,Ns) c128 and for the factored form
+// R[(b,f,t),s] = conj(V[f,t,i_b,s]) V[f,t,j_b,s].
+//
+// Algorithmic bytes: apply_R / adjoint_R read R once = 16*M*Ns B; the factored forms read V
+// once = 16*Nf*Nt*Nant*Ns B.  All reductions run in a fixed order (no atomics) so results
+// are bitwise reproducible.
+#include <algorithm>
+
+#include "common.h"
+
+namespace hydra {
+
+// ---------------------------------------------------------------- materialised R
+
+// out[r] = rowmul[r] * sum_s R[r,s] x[s]; one wave per row, 16-B loads contiguous over s.
+__global__ void __launch_bounds__(256)
+apply_R_kernel(const f64x2* __restrict__ R, long long m, int ns, const double* __restrict__ x,
+               const f64x2* __restrict__ rowmul, f64x2* __restrict__ out) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (long long r = (long long)blockIdx.x * 4 + wave; r < m; r += (long long)gridDim.x * 4) {
+    const f64x2* rp = R + (size_t)r * ns;
+    double sx = 0.0, sy = 0.0;
+    for (int s = lane; s < ns; s += 64) {
+      f64x2 v = rp[s];
+      double xs = x[s];
+      sx += v.x * xs;
+      sy += v.y * xs;
+    }
+    sx = wave_sum(sx);
+    sy = wave_sum(sy);
+    if (lane == 0) {
+      f64x2 o = {sx, sy};
+      if (rowmul) o = cmul(rowmul[r], o);
+      out[r] = o;
+    }
+  }
+}
+
+// partial[c][s] = sum over rows of chunk c of Re(conj(R[r,s]) z[r]); threads own columns.
+constexpr int ADJ_COLS = 4;  // columns per thread -> 1024 columns per workgroup pass
+__global__ void __launch_bounds__(256)
+adjoint_R_kernel(const f64x2* __restrict__ R, long long m, int ns, const f64x2* __restrict__ z,
+                 long long rows_per_chunk, double* __restrict__ partial) {
+  long long r0 = (long long)blockIdx.x * rows_per_chunk;
+  long long r1 = r0 + rows_per_chunk;
+  if (r1 > m) r1 = m;
+  int cbase = blockIdx.y * (256 * ADJ_COLS) + threadIdx.x;
+  double acc[ADJ_COLS];
+#pragma unroll
+  for (int c = 0; c < ADJ_COLS; ++c) acc[c] = 0.0;
+  for (long long r = r0; r < r1; ++r) {
+    f64x2 zr = z[r];
+    const f64x2* rp = R + (size_t)r * ns;
+#pragma unroll
+    for (int c = 0; c < ADJ_COLS; ++c) {
+      int s = cbase + c * 256;
+      if (s < ns) {
+        f64x2 v = rp[s];
+        acc[c] += v.x * zr.x + v.y * zr.y;
+      }
+    }
+  }
+#pragma unroll
+  for (int c = 0; c < ADJ_COLS; ++c) {
+    int s = cbase + c * 256;
+    if (s < ns) partial[(size_t)blockIdx.x * ns + s] = acc[c];
+  }
+}
+
+// out[s] = scale[s] * sum_c partial[c][s] + add[s]
+__global__ void __launch_bounds__(256)
+adjoint_reduce_kernel(const double* __restrict__ partial, int nchunk, int ns,
+                      const double* __restrict__ scale, const double* __restrict__ add,
+                      double* __restrict__ out) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= ns) return;
+  double sum = 0.0;
+  for (int c = 0; c < nchunk; ++c) sum += partial[(size_t)c * ns + s];
+  if (scale) sum *= scale[s];
+  if (add) sum += add[s];
+  out[s] = sum;
+}
+
+// z[r] = conj(gg[r]) * ((data[r] - model[r]) * w[r] + omega[r] * sqrt(w[r]))
+__global__ void __launch_bounds__(256)
+rhs_rows_kernel(const f64x2* __restrict__ data, const f64x2* __restrict__ model,
+                const double* __restrict__ w, const f64x2* __restrict__ omega,
+                const f64x2* __restrict__ gg, long long m, f64x2* __restrict__ z) {
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m;
+       r += (long long)gridDim.x * blockDim.x) {
+    f64x2 d = data[r];
+    if (model) {
+      f64x2 mo = model[r];
+      d.x -= mo.x;
+      d.y -= mo.y;
+    }
+    double wr = w ? w[r] : 1.0;
+    f64x2 y = {d.x * wr, d.y * wr};
+    if (omega) {
+      double rt = sqrt(wr);
+      f64x2 o = omega[r];
+      y.x += o.x * rt;
+      y.y += o.y * rt;
+    }
+    if (gg) y = cmul_conj(gg[r], y);
+    z[r] = y;
+  }
+}
+
+__global__ void __launch_bounds__(256)
+scale_rows_kernel(const f64x2* y, const double* __restrict__ w, long long m, f64x2* z) {
+  // z may alias y (in-place scaling)
+  for (long long r = (long long)blockIdx.x * blockDim.x + threadIdx.x; r < m;
+       r += (long long)gridDim.x * blockDim.x) {
+    f64x2 v = y[r];
+    double wr = w[r];
+    z[r] = f64x2{v.x * wr, v.y * wr};
+  }
+}
+
+// ---------------------------------------------------------------- factored form
+
+constexpr int VCH = 64;        // sources staged per pass
+constexpr int VPAD = VCH + 1;  // padded LDS row (16-B elements) -> rows land on different banks
+
+// out[b,ft] = rowmul[b,ft] * sum_s conj(V[ft,i_b,s]) V[ft,j_b,s] x[s]
+// One workgroup per (f,t): voltages staged 64 sources at a time, thread <-> baseline.
+__global__ void __launch_bounds__(256)
+apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
+               const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
+               const double* __restrict__ x, const f64x2* __restrict__ rowmul,
+               f64x2* __restrict__ out, int bl_per_thread) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  f64x2* s_v = reinterpret_cast<f64x2*>(smem);                       // [nant][VPAD]
+  double* s_x = reinterpret_cast<double*>(s_v + (size_t)nant * VPAD);  // [VCH]
+  int ft = blockIdx.x;
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f64x2* vft = V + (size_t)ft * nant * ns;
+  // up to 8 baselines per thread are accumulated in registers per pass over the sources
+  constexpr int MAXB = 8;
+  for (int bbase = 0; bbase < nbl; bbase += 256 * MAXB) {
+    f64x2 acc[MAXB];
+    int bi[MAXB], bj[MAXB];
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+      acc[q] = f64x2{0.0, 0.0};
+      int b = bbase + q * 256 + tid;
+      bool ok = b < nbl;
+      bi[q] = ok ? bl_i[b] : 0;
+      bj[q] = ok ? bl_j[b] : 0;
+    }
+    for (int s0 = 0; s0 < ns; s0 += VCH) {
+      __syncthreads();
+      int s = s0 + lane;
+      for (int a = wave; a < nant; a += 4)
+        s_v[a * VPAD + lane] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
+      if (tid < VCH) s_x[tid] = (s0 + tid < ns) ? x[s0 + tid] : 0.0;
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q) {
+        if (bbase + q * 256 < nbl) {  // uniform across the workgroup
+          const f64x2* pi = s_v + bi[q] * VPAD;
+          const f64x2* pj = s_v + bj[q] * VPAD;
+          f64x2 a = acc[q];
+          for (int k = 0; k < VCH; ++k) {
+            f64x2 r = cmul_conj(pi[k], pj[k]);
+            double xs = s_x[k];
+            a.x += r.x * xs;
+            a.y += r.y * xs;
+          }
+          acc[q] = a;
+        }
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+      int b = bbase + q * 256 + tid;
+      if (b < nbl) {
+        size_t o = (size_t)b * nft + ft;
+        f64x2 v = acc[q];
+        if (rowmul) v = cmul(rowmul[o], v);
+        out[o] = v;
+      }
+    }
+  }
+  (void)bl_per_thread;
+}
+
+// (nbl, nft) -> (nft, nbl) complex transpose so a workgroup reads one (f,t) slice contiguously
+__global__ void __launch_bounds__(256)
+ctranspose_kernel(const f64x2* __restrict__ in, int nbl, int nft, f64x2* __restrict__ out) {
+  size_t n = (size_t)nbl * nft;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n;
+       o += (size_t)gridDim.x * blockDim.x) {
+    size_t ft = o / nbl, b = o % nbl;
+    out[o] = in[b * (size_t)nft + ft];
+  }
+}
+
+// partial[split][s] = sum_{ft in split} sum_b Re( V_i,s conj(V_j,s) z[b,ft] )
+// Workgroup <-> (64-source chunk, ft range); 4 waves split the baselines, lanes own sources.
+__global__ void __launch_bounds__(256)
+adjoint_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
+                 const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
+                 const f64x2* __restrict__ zt, int ft_per_split, double* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  f64x2* s_v = reinterpret_cast<f64x2*>(smem);  // [nant][64]
+  double* s_red = reinterpret_cast<double*>(s_v + (size_t)nant * 64);  // [4][64]
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int s = blockIdx.x * 64 + lane;
+  int ft0 = blockIdx.y * ft_per_split;
+  int ft1 = ft0 + ft_per_split;
+  if (ft1 > nft) ft1 = nft;
+  double acc = 0.0;
+  for (int ft = ft0; ft < ft1; ++ft) {
+    const f64x2* vft = V + (size_t)ft * nant * ns;
+    const f64x2* zft = zt + (size_t)ft * nbl;
+    __syncthreads();
+    for (int a = wave; a < nant; a += 4)
+      s_v[a * 64 + lane] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
+    __syncthreads();
+    for (int b = wave; b < nbl; b += 4) {
+      f64x2 r = cmul_conj(s_v[bl_i[b] * 64 + lane], s_v[bl_j[b] * 64 + lane]);  // R[b,s]
+      f64x2 zb = zft[b];
+      acc += r.x * zb.x + r.y * zb.y;  // Re(conj(R) z)
+    }
+  }
+  __syncthreads();
+  s_red[wave * 64 + lane] = acc;
+  __syncthreads();
+  if (wave == 0 && s < ns) {
+    double t = (s_red[lane] + s_red[64 + lane]) + (s_red[128 + lane] + s_red[192 + lane]);
+    partial[(size_t)blockIdx.y * ns + s] = t;
+  }
+}
+
+static void adjoint_plan(long long m, int ns, int* nchunk, long long* rows_per_chunk) {
+  long long want = std::min<long long>(1024, std::max<long long>(1, m / 32));
+  long long per = (m + want - 1) / want;
+  *nchunk = (int)((m + per - 1) / per);
+  *rows_per_chunk = per;
+  (void)ns;
+}
+
+static void adjoint_V_plan(int nft, int ns, int* nsplit, int* per) {
+  int chunks = (ns + 63) / 64;
+  int want = std::max(1, std::min(nft, 2048 / chunks));
+  *per = (nft + want - 1) / want;
+  *nsplit = (nft + *per - 1) / *per;
+}
+
+}  // namespace hydra
+
+using namespace hydra;
+
+extern "C" {
+
+int hydra_apply_R(const double* R, long long m, int ns, const double* x, const double* rowmul,
+                  double* out, void* stream) {
+  HYDRA_CHECK_ARG(R && x && out && m > 0 && ns > 0, "hydra_apply_R: bad arguments (m=%lld ns=%d)", m,
+                  ns);
+  int grid = (int)std::min<long long>((m + 3) / 4, 8192);
+  apply_R_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(R), m, ns, x,
+                                                      reinterpret_cast<const f64x2*>(rowmul),
+                                                      reinterpret_cast<f64x2*>(out));
+  HYDRA_CHECK_LAUNCH("hydra_apply_R");
+  return HYDRA_OK;
+}
+
+size_t hydra_adjoint_workspace_bytes(long long m, int ns) {
+  if (m <= 0 || ns <= 0) return 0;
+  int nchunk;
+  long long per;
+  adjoint_plan(m, ns, &nchunk, &per);
+  return (size_t)nchunk * ns * sizeof(double);
+}
+
+int hydra_adjoint_R(const double* R, long long m, int ns, const double* z, const double* scale,
+                    const double* add, double* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  HYDRA_CHECK_ARG(R && z && out && m > 0 && ns > 0, "hydra_adjoint_R: bad arguments (m=%lld ns=%d)",
+                  m, ns);
+  size_t need = hydra_adjoint_workspace_bytes(m, ns);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_adjoint_R: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int nchunk;
+  long long per;
+  adjoint_plan(m, ns, &nchunk, &per);
+  double* partial = static_cast<double*>(workspace);
+  dim3 grid(nchunk, (ns + 256 * ADJ_COLS - 1) / (256 * ADJ_COLS));
+  adjoint_R_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(R), m, ns,
+                                                        reinterpret_cast<const f64x2*>(z), per,
+                                                        partial);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_R");
+  adjoint_reduce_kernel<<<(ns + 255) / 256, 256, 0, as_stream(stream)>>>(partial, nchunk, ns, scale,
+                                                                         add, out);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_R(reduce)");
+  return HYDRA_OK;
+}
+
+int hydra_rhs_rows(const double* data, const double* model, const double* w,
+                   const double* omega_n, const double* gg, long long m, double* z, void* stream) {
+  HYDRA_CHECK_ARG(data && z && m > 0, "hydra_rhs_rows: bad arguments");
+  int grid = (int)std::min<long long>((m + 255) / 256, 2048);
+  rhs_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+      reinterpret_cast<const f64x2*>(data), reinterpret_cast<const f64x2*>(model), w,
+      reinterpret_cast<const f64x2*>(omega_n), reinterpret_cast<const f64x2*>(gg), m,
+      reinterpret_cast<f64x2*>(z));
+  HYDRA_CHECK_LAUNCH("hydra_rhs_rows");
+  return HYDRA_OK;
+}
+
+int hydra_scale_rows(const double* y, const double* w, long long m, double* z, void* stream) {
+  HYDRA_CHECK_ARG(y && w && z && m > 0, "hydra_scale_rows: bad arguments");
+  int grid = (int)std::min<long long>((m + 255) / 256, 2048);
+  scale_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(y), w, m,
+                                                         reinterpret_cast<f64x2*>(z));
+  HYDRA_CHECK_LAUNCH("hydra_scale_rows");
+  return HYDRA_OK;
+}
+
+int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                  const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
+                  double* out, void* stream) {
+  HYDRA_CHECK_ARG(V && bl_i && bl_j && x && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
+                  "hydra_apply_V: bad arguments");
+  size_t lds = ((size_t)nant * VPAD) * 16 + VCH * 8;
+  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_apply_V: nant=%d exceeds the LDS staging limit", nant);
+  if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel), lds)) return rc_lds;
+  apply_V_kernel<<<nf * nt, 256, lds, as_stream(stream)>>>(
+      reinterpret_cast<const f64x2*>(V), nf * nt, nant, ns, bl_i, bl_j, nbl, x,
+      reinterpret_cast<const f64x2*>(rowmul), reinterpret_cast<f64x2*>(out), 0);
+  HYDRA_CHECK_LAUNCH("hydra_apply_V");
+  return HYDRA_OK;
+}
+
+size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns) {
+  if (nf <= 0 || nt <= 0 || nbl <= 0 || ns <= 0) return 0;
+  int nsplit, per;
+  adjoint_V_plan(nf * nt, ns, &nsplit, &per);
+  return align_up((size_t)nsplit * ns * sizeof(double), 256) + (size_t)nf * nt * nbl * 16;
+}
+
+int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                    const int32_t* bl_j, int nbl, const double* z, const double* scale,
+                    const double* add, double* out, void* workspace, size_t workspace_bytes,
+                    void* stream) {
+  HYDRA_CHECK_ARG(V && bl_i && bl_j && z && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
+                  "hydra_adjoint_V: bad arguments");
+  size_t need = hydra_adjoint_V_workspace_bytes(nf, nt, nbl, ns);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_adjoint_V: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  size_t lds = (size_t)nant * 64 * 16 + 4 * 64 * 8;
+  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_adjoint_V: nant=%d exceeds the LDS staging limit", nant);
+  int nft = nf * nt, nsplit, per;
+  adjoint_V_plan(nft, ns, &nsplit, &per);
+  HYDRA_CHECK_ARG(nsplit <= 65535, "hydra_adjoint_V: too many splits");
+  double* partial = static_cast<double*>(workspace);
+  f64x2* zt = reinterpret_cast<f64x2*>(static_cast<unsigned char*>(workspace) +
+                                       align_up((size_t)nsplit * ns * sizeof(double), 256));
+  hipStream_t st = as_stream(stream);
+  ctranspose_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const f64x2*>(z), nbl, nft, zt);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_V(transpose)");
+  if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_kernel), lds)) return rc_lds;
+  dim3 grid((ns + 63) / 64, nsplit);
+  adjoint_V_kernel<<<grid, 256, lds, st>>>(reinterpret_cast<const f64x2*>(V), nft, nant, ns, bl_i,
+                                           bl_j, nbl, zt, per, partial);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_V");
+  adjoint_reduce_kernel<<<(ns + 255) / 256, 256, 0, st>>>(partial, nsplit, ns, scale, add, out);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_V(reduce)");
+  return HYDRA_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,474 @@
+// Gram matrix Re(R^H W R) on the FP64 matrix cores (v_mfma_f64_16x16x4_f64), gfx950.
+//
+// Real SYRK over the stacked real matrix [Re(R'); Im(R')] with R' = diag(rows) R
+// (hydra/ptsrc_sampler.py:62-75, hydra/sh_sampler.py:393-398): K = 2M real rows, N = Ns.
+// Algorithmic work: 2 * M * Ns * (Ns+1) flops (lower triangle, both real and imaginary
+// parts).  Bound: FP64 MFMA.
+//
+// Layout of one MFMA: D(16x16) += A(16x4) B(4x16); lane l supplies A[l&15][l>>4] and
+// B[l>>4][l&15] and holds D[(l>>4) + 4*reg][l&15].  With A[i][k] = X[k][s0+i] and
+// B[k][j] = X[k][s0'+j] (X = stacked real operand) both operands have the SAME lane map:
+// lane -> (row k0 + (l>>4), column base + (l&15)).  So each lane produces its own operand
+// values directly in registers -- from one 16-byte complex load (materialised R) or from
+// two LDS reads of antenna voltages (fused form) -- and the real and imaginary parts of the
+// one complex value feed two consecutive MFMA k-steps.  No LDS transpose is needed.
+//
+// Workgroup: 256 threads = 4 waves as 2x2, output tile 128x128, wave tile 64x64
+// (4x4 MFMA tiles, 16 accumulators of 4 f64).  Only tiles of the lower triangle are
+// computed.  The row (K) range is split over workgroups; every workgroup writes its partial
+// tile to a slab and a second kernel sums the slabs in a fixed order (bitwise reproducible,
+// no atomics), mirrors the triangle and applies the prior epilogue.
+#include <algorithm>
+
+#include "common.h"
+
+namespace hydra {
+
+constexpr int TS = 128;            // workgroup tile edge
+constexpr int TILE_ELEMS = TS * TS;
+
+__device__ __forceinline__ f64x4 mfma(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+// p -> (ti, tj) with ti >= tj, p = ti (ti+1)/2 + tj
+__device__ __forceinline__ void tile_of(int p, int* ti, int* tj) {
+  int i = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+  while ((i + 1) * (i + 2) / 2 <= p) ++i;
+  while (i * (i + 1) / 2 > p) --i;
+  *ti = i;
+  *tj = p - i * (i + 1) / 2;
+}
+
+// Block id -> (tile, split) such that blocks with equal id % 8 (which share an XCD and its
+// L2 under round-robin dispatch) work on the same row range one tile after another.
+__device__ __forceinline__ void block_work(int id, int ntiles, int* tile, int* split) {
+  int xcd = id & 7, q = id >> 3;
+  *tile = q % ntiles;
+  *split = (q / ntiles) * 8 + xcd;
+}
+
+__device__ __forceinline__ void store_tile(double* __restrict__ slab, const f64x4 (&acc)[4][4],
+                                           int wr, int wc, int lane) {
+  int r0 = wr * 64 + (lane >> 4), c0 = wc * 64 + (lane & 15);
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        slab[(size_t)(r0 + mi * 16 + 4 * g) * TS + c0 + ni * 16] = acc[mi][ni][g];
+}
+
+// ------------------------------------------------------------------ materialised R
+
+// Operands of one k-step (4 rows x this wave's 64+64 columns), real and imaginary parts.
+struct Frag {
+  double are[4], aim[4], bre[4], bim[4];
+};
+
+template <bool EDGE>
+struct RowsProducer {
+  const f64x2* __restrict__ R;
+  const f64x2* __restrict__ rows;
+  long long k_end;
+  int ns;
+  int ca[4], cb[4];
+  double ma[4], mb[4];
+  int kr;
+  const f64x2* rp;
+  f64x2 c;
+
+  __device__ __forceinline__ void init(const f64x2* R_, const f64x2* rows_, long long k_end_,
+                                       int ns_, int colA, int colB, int lane) {
+    R = R_; rows = rows_; k_end = k_end_; ns = ns_; kr = lane >> 4;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      int a = colA + i * 16, b = colB + i * 16;
+      ma[i] = (!EDGE || a < ns) ? 1.0 : 0.0;
+      mb[i] = (!EDGE || b < ns) ? 1.0 : 0.0;
+      ca[i] = EDGE ? min(a, ns - 1) : a;
+      cb[i] = EDGE ? min(b, ns - 1) : b;
+    }
+  }
+  // select the row of this lane for the k-step starting at k0
+  __device__ __forceinline__ void begin(long long k0) {
+    long long row = k0 + kr;
+    bool valid = row < k_end;
+    if (!valid) row = k_end - 1;
+    c = f64x2{1.0, 0.0};
+    if (rows) c = rows[row];
+    if (!valid) c = f64x2{0.0, 0.0};
+    rp = R + (size_t)row * ns;
+  }
+  __device__ __forceinline__ void produce(int g, Frag& f) const {
+    f64x2 y = cmul(c, rp[ca[g]]);
+    f64x2 z = cmul(c, rp[cb[g]]);
+    if (EDGE) { y.x *= ma[g]; y.y *= ma[g]; z.x *= mb[g]; z.y *= mb[g]; }
+    f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
+  }
+};
+
+// 32 MFMAs of the current k-step interleaved with the production of the next step's
+// operands, so loads / VALU of step k+1 sit in the shadow of the matrix pipe.
+template <class P>
+__device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long long k_end,
+                                              f64x4 (&acc)[4][4]) {
+  Frag cur, nxt;
+  prod.begin(k_begin);
+#pragma unroll
+  for (int g = 0; g < 4; ++g) prod.produce(g, cur);
+  for (long long k0 = k_begin; k0 < k_end; k0 += 4) {
+    long long kn = (k0 + 4 < k_end) ? k0 + 4 : k0;  // last step re-produces itself (unused)
+    prod.begin(kn);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      prod.produce(g, nxt);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[g][ni] = mfma(cur.are[g], cur.bre[ni], acc[g][ni]);
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
+    }
+    cur = nxt;
+  }
+}
+
+template <bool EDGE>
+__device__ __forceinline__ void gram_rows_loop(const f64x2* __restrict__ R,
+                                               const f64x2* __restrict__ rows, long long k_begin,
+                                               long long k_end, int ns, int colA, int colB,
+                                               int lane, f64x4 (&acc)[4][4]) {
+  RowsProducer<EDGE> prod;
+  prod.init(R, rows, k_end, ns, colA, colB, lane);
+  mfma_pipeline(prod, k_begin, k_end, acc);
+}
+
+__global__ void __launch_bounds__(256, 2)
+gram_kernel(const f64x2* __restrict__ R, const f64x2* __restrict__ rows, long long m, int ns,
+            int ntiles, long long rows_per_split, double* __restrict__ slabs) {
+  int tile, split;
+  block_work(blockIdx.x, ntiles, &tile, &split);
+  int ti, tj;
+  tile_of(tile, &ti, &tj);
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  int wr = wave >> 1, wc = wave & 1;
+  long long k_begin = (long long)split * rows_per_split;
+  long long k_end = k_begin + rows_per_split;
+  if (k_end > m) k_end = m;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  int colA = ti * TS + wr * 64 + (lane & 15);
+  int colB = tj * TS + wc * 64 + (lane & 15);
+  if (k_begin < k_end) {
+    bool edge = (ti + 1) * TS > ns;  // ti >= tj, so only the row-tile can overhang
+    if (edge)
+      gram_rows_loop<true>(R, rows, k_begin, k_end, ns, colA, colB, lane, acc);
+    else
+      gram_rows_loop<false>(R, rows, k_begin, k_end, ns, colA, colB, lane, acc);
+  }
+  store_tile(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, wr, wc, lane);
+}
+
+// Sum the per-split slabs in order, mirror the lower triangle, apply the epilogue:
+//   prior_std: A = I + s_i G_ij s_j ; add_diag: A = G + diag(add) ; else G.
+__global__ void __launch_bounds__(256)
+gram_finish_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ns,
+                   const double* __restrict__ prior_std, const double* __restrict__ add_diag,
+                   double* __restrict__ G) {
+  int tile = blockIdx.x;
+  int ti, tj;
+  tile_of(tile, &ti, &tj);
+  for (int e = threadIdx.x; e < TILE_ELEMS; e += blockDim.x) {
+    int r = e / TS, c = e % TS;
+    int gi = ti * TS + r, gj = tj * TS + c;
+    if (gi >= ns || gj >= ns) continue;
+    if (ti == tj && c > r) continue;
+    double sum = 0.0;
+    for (int s = 0; s < nsplit; ++s) sum += slabs[((size_t)s * ntiles + tile) * TILE_ELEMS + e];
+    if (prior_std) {
+      sum = prior_std[gi] * sum * prior_std[gj];
+      if (gi == gj) sum = 1.0 + sum;
+    } else if (add_diag && gi == gj) {
+      sum += add_diag[gi];
+    }
+    G[(size_t)gi * ns + gj] = sum;
+    if (gi != gj) G[(size_t)gj * ns + gi] = sum;
+  }
+}
+
+// Split plan shared by the launch and the workspace query.  `nunits` rows (or (f,t) slices)
+// are cut into `nsplit` (multiple of 8, see block_work) ranges of `per_split` units each,
+// aiming at ~4096 workgroups and at least `min_units` units per range.
+// in-place epilogue on a full (ns,ns) matrix (used after a cross-GPU sum of raw Grams)
+__global__ void __launch_bounds__(256)
+prior_epilogue_kernel(double* __restrict__ G, int ns, const double* __restrict__ prior_std,
+                      const double* __restrict__ add_diag) {
+  size_t n = (size_t)ns * ns;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / ns), j = (int)(e % ns);
+    double v = G[e];
+    if (prior_std) {
+      v = prior_std[i] * v * prior_std[j];
+      if (i == j) v = 1.0 + v;
+    } else if (add_diag && i == j) {
+      v += add_diag[i];
+    }
+    G[e] = v;
+  }
+}
+
+static void gram_plan(long long nunits, int ns, int* ntiles, int* nsplit, long long* per_split,
+                      long long unit_align, long long min_units) {
+  int nt1 = (ns + TS - 1) / TS;
+  *ntiles = nt1 * (nt1 + 1) / 2;
+  long long want = std::max<long long>(8, 4096 / *ntiles);
+  want = (want + 7) / 8 * 8;
+  long long cap = std::max<long long>(8, (nunits / min_units) / 8 * 8);
+  want = std::min<long long>(std::min<long long>(want, cap), 512);
+  long long per = (nunits + want - 1) / want;
+  per = (per + unit_align - 1) / unit_align * unit_align;
+  *nsplit = (int)want;
+  *per_split = per;
+}
+
+// ------------------------------------------------------------------ fused (factored) form
+
+// sqrtw_t[ft][b] = sqrt(inv_noise[b][ft]) (or 1): contiguous per (f,t) slice for LDS staging
+__global__ void __launch_bounds__(256)
+sqrtw_transpose_kernel(const double* __restrict__ w, int nbl, int nft, double* __restrict__ out) {
+  size_t n = (size_t)nbl * nft;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n;
+       o += (size_t)gridDim.x * blockDim.x) {
+    size_t ft = o / nbl, b = o % nbl;
+    out[o] = w ? sqrt(w[b * (size_t)nft + ft]) : 1.0;
+  }
+}
+
+struct FusedProducer {
+  const f64x2* s_u;
+  const double* s_sw;
+  const uint32_t* s_info;
+  int nrows, kr, offA, offB;
+  const f64x2* pi;
+  const f64x2* pj;
+  double sw;
+
+  __device__ __forceinline__ void begin(long long k0) {
+    int r = (int)k0 + kr;
+    bool valid = r < nrows;
+    uint32_t info = s_info[valid ? r : 0];
+    sw = valid ? s_sw[r] : 0.0;
+    pi = s_u + (info & 0xffffu) * 256;
+    pj = s_u + (info >> 16) * 256;
+  }
+  // R'[r,s] = sqrt(w_r) conj(u_i,s) u_j,s with u_a = conj(g_a) v_a staged in LDS
+  __device__ __forceinline__ void produce(int g, Frag& f) const {
+    f64x2 ui = pi[offA + g * 16], uj = pj[offA + g * 16];
+    ui.x *= sw; ui.y *= sw;
+    f64x2 y = cmul_conj(ui, uj);
+    f64x2 wi = pi[offB + g * 16], wj = pj[offB + g * 16];
+    wi.x *= sw; wi.y *= sw;
+    f64x2 z = cmul_conj(wi, wj);
+    f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
+  }
+};
+
+// LDS: u[nrows_lds][256] complex (cols 0..127: A side = row-tile sources; 128..255: B side)
+//      info[max_rows] uint32 (ldsrow_i | ldsrow_j << 16), sw[max_rows] f64
+__global__ void __launch_bounds__(256, 1)
+gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
+                  const f64x2* __restrict__ gains, const double* __restrict__ sqrtw_t, int nbl,
+                  const int32_t* __restrict__ seg, int nseg, const int32_t* __restrict__ rowtab,
+                  int max_lds_rows, int max_seg_rows, int ntiles, int ft_per_split,
+                  double* __restrict__ slabs) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  f64x2* s_u = reinterpret_cast<f64x2*>(smem);
+  double* s_sw = reinterpret_cast<double*>(smem + (size_t)max_lds_rows * 256 * 16);
+  uint32_t* s_info = reinterpret_cast<uint32_t*>(s_sw + max_seg_rows);
+
+  int tile, split;
+  block_work(blockIdx.x, ntiles, &tile, &split);
+  int ti, tj;
+  tile_of(tile, &ti, &tj);
+  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int wr = wave >> 1, wc = wave & 1;
+  int ft_begin = split * ft_per_split;
+  int ft_end = ft_begin + ft_per_split;
+  if (ft_end > nft) ft_end = nft;
+
+  f64x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  // column this thread stages into LDS
+  int scol = (tid < 128) ? ti * TS + tid : tj * TS + (tid - 128);
+  bool scol_ok = scol < ns;
+  const int kr = lane >> 4;
+  const int offA = wr * 64 + (lane & 15);
+  const int offB = 128 + wc * 64 + (lane & 15);
+
+  for (int ft = ft_begin; ft < ft_end; ++ft) {
+    const f64x2* vft = V + (size_t)ft * nant * ns;
+    for (int sg = 0; sg < nseg; ++sg) {
+      const int32_t* sd = seg + 6 * sg;
+      int i0 = sd[0], ni = sd[1], j0 = sd[2], nj = sd[3], row0 = sd[4], nrows = sd[5];
+      int nload = (j0 == i0) ? ni : ni + nj;
+      __syncthreads();  // previous segment fully consumed
+      for (int a = 0; a < nload; ++a) {
+        int ant = (a < ni) ? i0 + a : j0 + (a - ni);
+        f64x2 u = {0.0, 0.0};
+        if (scol_ok) {
+          u = vft[(size_t)ant * ns + scol];
+          if (gains) {
+            f64x2 g = gains[(size_t)ant * nft + ft];
+            u = cmul_conj(g, u);  // conj(g_a) v_a
+          }
+        }
+        s_u[a * 256 + tid] = u;
+      }
+      for (int r = tid; r < nrows; r += 256) {
+        const int32_t* rt = rowtab + 3 * (size_t)(row0 + r);
+        s_info[r] = (uint32_t)rt[0] | ((uint32_t)rt[1] << 16);
+        s_sw[r] = sqrtw_t[(size_t)ft * nbl + rt[2]];
+      }
+      __syncthreads();
+
+      FusedProducer prod;
+      prod.s_u = s_u; prod.s_sw = s_sw; prod.s_info = s_info;
+      prod.nrows = nrows; prod.kr = kr; prod.offA = offA; prod.offB = offB;
+      mfma_pipeline(prod, 0, nrows, acc);
+    }
+  }
+  store_tile(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, wr, wc, lane);
+}
+
+}  // namespace hydra
+
+using namespace hydra;
+
+extern "C" {
+
+size_t hydra_gram_workspace_bytes(long long m, int ns) {
+  if (m <= 0 || ns <= 0) return 0;
+  int ntiles, nsplit;
+  long long per;
+  gram_plan(m, ns, &ntiles, &nsplit, &per, 4, 64);
+  return (size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double);
+}
+
+int hydra_gram(const double* R, const double* rows, long long m, int ns, const double* prior_std,
+               const double* add_diag, double* G, void* workspace, size_t workspace_bytes,
+               void* stream) {
+  HYDRA_CHECK_ARG(R && G && m > 0 && ns > 0, "hydra_gram: bad arguments (m=%lld ns=%d)", m, ns);
+  HYDRA_CHECK_ARG(!(prior_std && add_diag), "hydra_gram: give at most one of prior_std, add_diag");
+  size_t need = hydra_gram_workspace_bytes(m, ns);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_gram: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int ntiles, nsplit;
+  long long per;
+  gram_plan(m, ns, &ntiles, &nsplit, &per, 4, 64);
+  double* slabs = static_cast<double*>(workspace);
+  gram_kernel<<<ntiles * nsplit, 256, 0, as_stream(stream)>>>(
+      reinterpret_cast<const f64x2*>(R), reinterpret_cast<const f64x2*>(rows), m, ns, ntiles, per,
+      slabs);
+  HYDRA_CHECK_LAUNCH("hydra_gram");
+  gram_finish_kernel<<<ntiles, 256, 0, as_stream(stream)>>>(slabs, nsplit, ntiles, ns, prior_std,
+                                                            add_diag, G);
+  HYDRA_CHECK_LAUNCH("hydra_gram(finish)");
+  return HYDRA_OK;
+}
+
+int hydra_prior_epilogue(double* G, int ns, const double* prior_std, const double* add_diag,
+                         void* stream) {
+  HYDRA_CHECK_ARG(G && ns > 0 && !(prior_std && add_diag), "hydra_prior_epilogue: bad arguments");
+  size_t n = (size_t)ns * ns;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  prior_epilogue_kernel<<<grid, 256, 0, as_stream(stream)>>>(G, ns, prior_std, add_diag);
+  HYDRA_CHECK_LAUNCH("hydra_prior_epilogue");
+  return HYDRA_OK;
+}
+
+size_t hydra_gram_fused_workspace_bytes(int nf, int nt, int nbl, int ns) {
+  if (nf <= 0 || nt <= 0 || nbl <= 0 || ns <= 0) return 0;
+  int ntiles, nsplit;
+  long long per;
+  gram_plan((long long)nf * nt, ns, &ntiles, &nsplit, &per, 1, 1);
+  size_t slabs = (size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double);
+  return align_up(slabs, 256) + (size_t)nf * nt * nbl * sizeof(double);
+}
+
+int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const double* gains,
+                     const double* inv_noise, int nbl, const int32_t* seg_host,
+                     const int32_t* rowtab_host, const int32_t* seg, const int32_t* rowtab,
+                     int nseg, int nrows, const double* prior_std,
+                     const double* add_diag, double* G, void* workspace, size_t workspace_bytes,
+                     void* stream) {
+  HYDRA_CHECK_ARG(V && G && seg_host && rowtab_host && seg && rowtab,
+                  "hydra_gram_fused: null pointer argument");
+  HYDRA_CHECK_ARG(nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0 && nseg > 0 && nrows > 0,
+                  "hydra_gram_fused: sizes must be positive");
+  HYDRA_CHECK_ARG(!(prior_std && add_diag),
+                  "hydra_gram_fused: give at most one of prior_std, add_diag");
+  // validate the segment table on the host: it drives LDS indexing in the kernel
+  int max_lds_rows = 0, max_seg_rows = 0;
+  long long total = 0;
+  for (int s = 0; s < nseg; ++s) {
+    const int32_t* d = seg_host + 6 * s;
+    HYDRA_CHECK_ARG(d[0] >= 0 && d[1] > 0 && d[0] + d[1] <= nant && d[2] >= 0 && d[3] > 0 &&
+                        d[2] + d[3] <= nant && d[4] == total && d[5] > 0,
+                    "hydra_gram_fused: malformed segment %d", s);
+    int nload = (d[2] == d[0]) ? d[1] : d[1] + d[3];
+    HYDRA_CHECK_ARG(d[2] != d[0] || d[3] == d[1], "hydra_gram_fused: segment %d aliases unequal blocks", s);
+    for (int r = 0; r < d[5]; ++r) {
+      const int32_t* rt = rowtab_host + 3 * (total + r);
+      HYDRA_CHECK_ARG(rt[0] >= 0 && rt[0] < nload && rt[1] >= 0 && rt[1] < nload && rt[2] >= 0 &&
+                          rt[2] < nbl,
+                      "hydra_gram_fused: row %lld of segment %d out of range", total + r, s);
+    }
+    max_lds_rows = std::max(max_lds_rows, nload);
+    max_seg_rows = std::max(max_seg_rows, (int)d[5]);
+    total += d[5];
+  }
+  HYDRA_CHECK_ARG(total == nrows, "hydra_gram_fused: segments cover %lld rows, table has %d", total,
+                  nrows);
+  size_t lds = (size_t)max_lds_rows * 256 * 16 + (size_t)max_seg_rows * 12 + 16;
+  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_gram_fused: segment needs %zu bytes of LDS (> 160 KiB)",
+                  lds);
+  size_t need = hydra_gram_fused_workspace_bytes(nf, nt, nbl, ns);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_gram_fused: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int nft = nf * nt;
+  int ntiles, nsplit;
+  long long per;
+  gram_plan(nft, ns, &ntiles, &nsplit, &per, 1, 1);
+  double* slabs = static_cast<double*>(workspace);
+  size_t slab_bytes = align_up((size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double), 256);
+  double* sqrtw_t = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + slab_bytes);
+  hipStream_t st = as_stream(stream);
+  sqrtw_transpose_kernel<<<2048, 256, 0, st>>>(inv_noise, nbl, nft, sqrtw_t);
+  HYDRA_CHECK_LAUNCH("hydra_gram_fused(sqrtw)");
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_fused_kernel),
+                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  if (e != hipSuccess)
+    return fail(HYDRA_ERR_HIP, "hydra_gram_fused: cannot reserve %zu bytes of LDS: %s", lds,
+                hipGetErrorString(e));
+  gram_fused_kernel<<<ntiles * nsplit, 256, lds, st>>>(
+      reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
+      sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
+  HYDRA_CHECK_LAUNCH("hydra_gram_fused");
+  gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G);
+  HYDRA_CHECK_LAUNCH("hydra_gram_fused(finish)");
+  return HYDRA_OK;
+}
+
+}  // extern "C"

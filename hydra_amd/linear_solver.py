@@ -1,0 +1,233 @@
+"""
+Linear solvers of the GCR system on MI355X -- drop-in for ``hydra.linear_solver``
+(reference: hydra/linear_solver.py).
+
+``cg`` keeps the reference's algorithm (linear_solver.py:378-509): no
+preconditioner, convergence tested before each iteration (element-wise by
+default), ``x`` returned after ``maxiters`` regardless.  The iteration state
+(x, r, p, r.r, done flag, iteration count) lives on the GPU and one fused kernel
+per iteration does both dot products, the three vector updates and the test
+(csrc/solver.hip); a converged solve turns later enqueued steps into no-ops, so
+the host only reads the flag every ``check_every`` iterations.
+
+``cg_mpi`` / ``setup_mpi_blocks`` / ``collect_linear_sys_blocks`` / ``matvec_mpi``
+keep the reference's 2-D block layout over ranks (linear_solver.py:11-375) on
+``hydra_amd._dist.Comm`` (torch.distributed: RCCL on GPUs, gloo on CPUs).
+"""
+import numpy as np
+import torch
+
+from . import _dev
+
+CHECK_EVERY = 16
+
+
+def _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0):
+    A = _dev.f64(Amat)
+    b = _dev.f64(bvec)
+    n = b.numel()
+    assert tuple(A.shape) == (n, n)
+    x = _dev.f64(x0).clone() if x0 is not None else torch.zeros_like(b)
+    ws = _dev.workspace(_dev._lib.query("hydra_cg_workspace_bytes", n))
+    import ctypes
+    iters = ctypes.c_int(0)
+    _dev.call("hydra_cg_solve_dense", _dev.ptr(A), _dev.ptr(b), _dev.ptr(x), n, int(maxiters),
+              float(abs_tol), int(bool(use_norm_tol)), CHECK_EVERY, ctypes.byref(iters),
+              _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+    return x, iters.value
+
+
+def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
+    """CG with a caller-supplied operator.  The operator is called with the same kind of array
+    as ``bvec`` (numpy or GPU tensor) and may return either."""
+    as_torch = _dev.is_torch(bvec)
+    b = _dev.f64(bvec)
+    n = b.numel()
+    x = _dev.f64(x0).clone() if x0 is not None else torch.zeros_like(b)
+    r = torch.empty_like(b)
+    p = torch.empty_like(b)
+    st = _dev.zeros((8,), torch.float64)
+    sp = _dev.stream_ptr()
+
+    def op(v):
+        out = linear_op(v if as_torch else v.cpu().numpy())
+        return _dev.f64(out)
+
+    _dev.call("hydra_cg_init", n, _dev.ptr(b), _dev.ptr(op(x)), _dev.ptr(r), _dev.ptr(p),
+              _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
+    it = 0
+    every = CHECK_EVERY if as_torch else 1     # a numpy operator synchronises every call anyway
+    while True:
+        if float(st[1].item()) != 0.0 or it >= maxiters:
+            break
+        for _ in range(min(every, maxiters - it)):
+            ap = op(p)
+            _dev.call("hydra_cg_step", n, _dev.ptr(ap), _dev.ptr(x), _dev.ptr(r), _dev.ptr(p),
+                      _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
+            it += 1
+    return x, int(st[2].item())
+
+
+def cg(Amat, bvec, maxiters=1000, abs_tol=1e-8, use_norm_tol=False, x0=None, linear_op=None,
+       comm=None, return_iters=False):
+    """Conjugate-gradient solve of ``Amat x = bvec`` (linear_solver.py:378-509).
+
+    ``linear_op`` (callable) replaces ``Amat`` when given.  With ``comm`` every rank runs the
+    same iteration on the (already synchronised) operator results and the root's solution is
+    broadcast at the end, so all ranks return the same ``x`` as in the reference (:506-508).
+    """
+    if x0 is not None:
+        assert tuple(x0.shape) == tuple(bvec.shape), (
+            "Initial guess x0 has a different shape to bvec")
+        assert x0.dtype == bvec.dtype, "Initial guess x0 has a different type to bvec"
+    if linear_op is None:
+        x, iters = _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0)
+    else:
+        x, iters = _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op)
+    if comm is not None:
+        comm.barrier()
+        comm.bcast_(x, root=0)
+    out = _dev.like(bvec, x)
+    return (out, iters) if return_iters else out
+
+
+def solve_dense(Amat, bvec):
+    """Dense fallback: ``scipy.linalg.solve(A, b, assume_a='her')`` of the driver
+    (example.py:944) for the symmetric positive-definite GCR operator, by blocked Cholesky
+    on the GPU.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
+    A = _dev.f64(Amat).clone()
+    b = _dev.f64(bvec).clone()
+    n = b.numel()
+    assert tuple(A.shape) == (n, n)
+    info = _dev.zeros((1,), torch.int32)
+    _dev.call("hydra_chol_solve", _dev.ptr(A), _dev.ptr(b), n, _dev.ptr(info), _dev.stream_ptr())
+    if int(info.item()) != 0:
+        raise np.linalg.LinAlgError("matrix is not positive definite")
+    return _dev.like(bvec, b)
+
+
+# ------------------------------------------------------------------ 2-D block CG over ranks
+
+def matvec_mpi(comm_row, mat_block, vec_block):
+    """Row-block matrix-vector product summed over the ranks of a block row
+    (linear_solver.py:11-49)."""
+    A = _dev.f64(mat_block)
+    v = _dev.f64(vec_block)
+    y = torch.empty(A.shape[0], dtype=torch.float64, device=A.device)
+    _gemv_rect(A, v, y)
+    comm_row.allreduce_(y)
+    return _dev.like(vec_block, y)
+
+
+def _gemv_rect(A, v, y):
+    n = A.shape[0]
+    assert A.shape[0] == A.shape[1] == v.numel(), "blocks are square (linear_solver.py:132-134)"
+    _dev.call("hydra_gemv", _dev.ptr(A), n, _dev.ptr(v), _dev.ptr(y), _dev.stream_ptr())
+
+
+def setup_mpi_blocks(comm, matrix_shape, split=1):
+    """Block layout and sub-communicators (linear_solver.py:52-137): returns
+    ((active, row, col, diag) communicators, block_map, block_shape)."""
+    assert len(matrix_shape) == 2, "'matrix_shape' must be a tuple with 2 entries"
+    assert matrix_shape[0] == matrix_shape[1], "Only square matrices are currently supported"
+    myid, nworkers = comm.Get_rank(), comm.Get_size()
+    nblocks = split * split
+    assert nworkers >= nblocks, "Specified more blocks than workers"
+    workers = np.arange(nblocks).reshape((split, split))
+    block_map = {int(w): (int(w) // split, int(w) % split) for w in workers.flatten()}
+    # sub-groups must be created collectively by every rank (torch.distributed.new_group)
+    comm_active = comm.Create(workers.flatten().tolist())
+    rows = [comm.Create(workers[i, :].tolist()) for i in range(split)]
+    cols = [comm.Create(workers[:, j].tolist()) for j in range(split)]
+    comm_diag = comm.Create(np.diag(workers).tolist())
+    if myid >= nblocks:
+        return None, {}, {}
+    myrow, mycol = block_map[myid]
+    block_rows = int(np.ceil(matrix_shape[0] / split))
+    block_cols = int(np.ceil(matrix_shape[1] / split))
+    assert block_rows == block_cols, "Current implementation assumes that blocks are square"
+    comms = (comm_active, rows[myrow], cols[mycol], comm_diag if myrow == mycol else None)
+    return comms, block_map, (block_rows, block_cols)
+
+
+def collect_linear_sys_blocks(comm, block_map, block_shape, Amat=None, bvec=None,
+                              verbose=False):
+    """Root slices (A, b) into zero-padded blocks and sends one to each active rank; the b
+    block is indexed by the block COLUMN (linear_solver.py:140-235)."""
+    myid = comm.Get_rank()
+    used = sorted(block_map.keys())
+    if myid not in used:
+        return None, None
+    br, bc = block_shape
+    my_A = np.zeros((br, bc), dtype=np.float64)
+    my_b = np.zeros((br,), dtype=np.float64)
+    if myid == 0:
+        Amat = np.asarray(Amat.cpu() if _dev.is_torch(Amat) else Amat)
+        bvec = np.asarray(bvec.cpu() if _dev.is_torch(bvec) else bvec)
+        for w in used:
+            wrow, wcol = block_map[w]
+            ii, jj = wrow * br, wcol * bc
+            iip, jjp = min(ii + br, Amat.shape[0]), min(jj + bc, Amat.shape[1])
+            Ab = np.zeros_like(my_A)
+            bb = np.zeros_like(my_b)
+            Ab[: iip - ii, : jjp - jj] = Amat[ii:iip, jj:jjp]
+            bb[: jjp - jj] = bvec[jj:jjp]
+            if w == 0:
+                my_A, my_b = Ab, bb
+            else:
+                comm.Send(Ab, dest=w)
+                comm.Send(bb, dest=w)
+        if verbose:
+            print("All send operations completed.")
+    else:
+        comm.Recv(my_A, source=0)
+        comm.Recv(my_b, source=0)
+        if verbose:
+            print("Worker %d finished receive" % myid)
+    return my_A, my_b
+
+
+def cg_mpi(comm_groups, Amat_block, bvec_block, vec_size, block_map, maxiters=1000,
+           abs_tol=1e-8):
+    """Block-distributed CG (linear_solver.py:238-375): x0 = 0, one block of A per rank,
+    row all-reduce for the product, column broadcast of p, scalar all-reduces over the
+    diagonal ranks.  Returns the full solution on diagonal ranks, None elsewhere."""
+    if comm_groups is None:
+        return None
+    comm_active, comm_row, comm_col, comm_diag = comm_groups
+    myid = comm_active.Get_rank()
+    myrow, mycol = block_map[myid]
+    A = _dev.f64(Amat_block)
+    r = _dev.f64(bvec_block).clone()
+    p = r.clone()
+    x = torch.zeros_like(r)
+    y = torch.empty_like(r)
+    niter = 0
+    while niter < maxiters:
+        conv = torch.all(torch.abs(r) < abs_tol).to(torch.int32).reshape(1)
+        comm_active.allreduce_(conv, op="min")
+        if int(conv.item()) != 0:
+            break
+        if myrow != mycol:
+            p.zero_()
+        comm_col.bcast_(p, root=mycol)      # group-rank of the diagonal member of this column
+        _gemv_rect(A, p, y)
+        comm_row.allreduce_(y)
+        if myrow == mycol:
+            sc = torch.stack([torch.dot(r, r), torch.dot(p, y)])
+            comm_diag.allreduce_(sc)
+            alpha = sc[0] / sc[1]
+            x = x + alpha * p
+            r = r - alpha * y
+            rn = torch.dot(r, r).reshape(1)
+            comm_diag.allreduce_(rn)
+            p = r + (rn[0] / sc[0]) * p
+        comm_active.barrier()
+        niter += 1
+    x_all = None
+    if myrow == mycol:
+        parts = comm_diag.allgather(x)
+        x_all = torch.cat(parts)[:vec_size]
+        x_all = _dev.like(bvec_block, x_all)
+    comm_active.barrier()
+    return x_all

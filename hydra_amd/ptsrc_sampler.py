@@ -1,0 +1,250 @@
+"""
+Point-source amplitude head on MI355X -- drop-in for ``hydra.ptsrc_sampler``
+(reference: hydra/ptsrc_sampler.py).
+
+    calc_proj_operator(...)  -> R (Nbl, Nf, Nt, Nsrc)          ptsrc_sampler.py:143-215
+    precompute_mpi(...)      -> (A, b) of the GCR system        ptsrc_sampler.py:17-140
+        A = 1 + S^1/2 Re(R^H N^-1 R) S^1/2
+        b = S^1/2 Re(R^H (N^-1 r + N^-1/2 w_n)) + w_a,  r = d - R 1
+
+Extensions that do not change the reference call signatures:
+  * ``calc_proj_operator(..., materialize=False)`` returns a ``FactoredProj`` (antenna
+    voltages + baseline tables) that ``precompute_mpi`` accepts as ``proj_chunk``; the
+    operator is then generated inside the kernels and never stored (at BASELINE config 2
+    the materialised R would be 273 GB).
+  * ``precompute_mpi(..., omega_n=, omega_a=)`` inject the fluctuation vectors; when
+    omitted they are drawn from the global numpy RNG in the reference's order
+    (ptsrc_sampler.py:109-116,138) so a seeded run reproduces the reference.
+"""
+import numpy as np
+import torch
+
+from . import _dev, _tables
+from .vis_simulator import voltages_for
+
+
+#: when set to a list, ``precompute_mpi`` appends a (start, end) pair of HIP events (recorded on
+#: the stream the kernels run on) around each Gram launch -- used by bench.py for the roofline
+GRAM_EVENTS = None
+
+
+def _timed_gram(fn):
+    if GRAM_EVENTS is None:
+        return fn()
+    start = torch.cuda.Event(enable_timing=True)
+    end = torch.cuda.Event(enable_timing=True)
+    start.record()
+    out = fn()
+    end.record()
+    GRAM_EVENTS.append((start, end))
+    return out
+
+
+class FactoredProj:
+    """The projection operator in factored form: R[(b,f,t),s] = conj(V[f,t,i_b,s]) V[f,t,j_b,s].
+
+    ``V`` (Nf,Nt,Nant,Ns) complex128 GPU tensor; ``bl_i``/``bl_j`` antenna index per baseline.
+    ``shape`` is the shape the materialised operator would have."""
+
+    def __init__(self, V, bl_i, bl_j):
+        self.V = V
+        self.bl_i_host = np.ascontiguousarray(bl_i, dtype=np.int32)
+        self.bl_j_host = np.ascontiguousarray(bl_j, dtype=np.int32)
+        self.bl_i = _dev.i32(self.bl_i_host)
+        self.bl_j = _dev.i32(self.bl_j_host)
+        nf, nt, nant, ns = V.shape
+        self.shape = (self.bl_i_host.size, nf, nt, ns)
+        self.seg_host, self.rowtab_host = _tables.build_segments(bl_i, bl_j, nant)
+        self.seg = _dev.i32(self.seg_host)
+        self.rowtab = _dev.i32(self.rowtab_host)
+
+    @property
+    def nbytes_materialised(self):
+        return int(np.prod(self.shape)) * 16
+
+    def materialize(self):
+        """R (Nbl,Nf,Nt,Ns) complex128 GPU tensor (csrc/response.hip)."""
+        nf, nt, nant, ns = self.V.shape
+        nbl = self.shape[0]
+        R = _dev.empty(self.shape, torch.complex128)
+        _dev.call("hydra_response", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(self.bl_i),
+                  _dev.ptr(self.bl_j), nbl, _dev.ptr(R), _dev.stream_ptr())
+        return R
+
+    def apply(self, x, rowmul=None):
+        """(Nbl,Nf,Nt) = rowmul * (R @ x) without materialising R."""
+        nf, nt, nant, ns = self.V.shape
+        nbl = self.shape[0]
+        out = _dev.empty((nbl, nf, nt), torch.complex128)
+        _dev.call("hydra_apply_V", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(self.bl_i),
+                  _dev.ptr(self.bl_j), nbl, _dev.ptr(_dev.f64(x)), _dev.ptr(rowmul),
+                  _dev.ptr(out), _dev.stream_ptr())
+        return out
+
+    def adjoint(self, z, scale=None, add=None):
+        """(Ns,) = scale * Re(R^H z) + add without materialising R."""
+        nf, nt, nant, ns = self.V.shape
+        nbl = self.shape[0]
+        nbytes = _dev._lib.query("hydra_adjoint_V_workspace_bytes", nf, nt, nbl, ns)
+        ws = _dev.workspace(nbytes)
+        out = _dev.empty((ns,), torch.float64)
+        _dev.call("hydra_adjoint_V", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(self.bl_i),
+                  _dev.ptr(self.bl_j), nbl, _dev.ptr(z), _dev.ptr(scale), _dev.ptr(add),
+                  _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+        return out
+
+    def gram(self, gains, inv_noise, prior_std=None, add_diag=None):
+        """Re(R'^H N^-1 R') on the FP64 matrix cores, R' = diag(g_i conj g_j) R."""
+        nf, nt, nant, ns = self.V.shape
+        nbl = self.shape[0]
+        nbytes = _dev._lib.query("hydra_gram_fused_workspace_bytes", nf, nt, nbl, ns)
+        ws = _dev.workspace(nbytes)
+        G = _dev.empty((ns, ns), torch.float64)
+        _dev.call("hydra_gram_fused", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(gains),
+                  _dev.ptr(inv_noise), nbl, _dev.host_ptr(self.seg_host),
+                  _dev.host_ptr(self.rowtab_host), _dev.ptr(self.seg), _dev.ptr(self.rowtab),
+                  int(self.seg_host.shape[0]), int(self.rowtab_host.shape[0]),
+                  _dev.ptr(prior_std), _dev.ptr(add_diag), _dev.ptr(G), _dev.ptr(ws), ws.numel(),
+                  _dev.stream_ptr())
+        return G
+
+
+def calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, beams,
+                       latitude=-0.5361913261514378, materialize=True):
+    """Visibility vector of each point source per (baseline, frequency, time): the projection
+    operator from source amplitudes to visibilities, gains not included
+    (ptsrc_sampler.py:143-215).  ``freqs`` in MHz, ``times`` = LSTs in rad.
+
+    Returns (Nbl, Nf, Nt, Nsrc) complex128 (numpy, or a GPU tensor if ``fluxes`` is one), or a
+    ``FactoredProj`` when ``materialize=False``."""
+    freqs_h = np.asarray(freqs.cpu() if _dev.is_torch(freqs) else freqs, dtype=np.float64)
+    V = voltages_for(ant_pos, fluxes, ra, dec, freqs_h * 1e6, times, beams, latitude)
+    names = list(ant_pos.keys())
+    bl_i = np.array([names.index(bl[0]) for bl in antpairs], dtype=np.int32)
+    bl_j = np.array([names.index(bl[1]) for bl in antpairs], dtype=np.int32)
+    # The reference only fills vis[..., i, j>=i, :] (vis_simulator.py:281-289), so a pair listed
+    # with idx1 > idx2 picks up zeros (ptsrc_sampler.py:209-213).
+    flipped = bl_i > bl_j
+    proj = FactoredProj(V, bl_i, bl_j)
+    if not materialize:
+        if flipped.any():
+            raise ValueError("antpairs must list each pair in antenna-dict order (idx1 <= idx2) "
+                             "for the factored operator")
+        return proj
+    R = proj.materialize()
+    if flipped.any():
+        R[torch.as_tensor(np.nonzero(flipped)[0], device=R.device)] = 0
+    return _dev.like(fluxes, R)
+
+
+def _draw_omega_n(shape, realisation):
+    # ptsrc_sampler.py:109-116: Re then Im from the global RNG
+    sw = 1.0 if realisation else 0.0
+    return sw * (1.0 * np.random.randn(*shape) + 1.0j * np.random.randn(*shape)) / np.sqrt(2.0)
+
+
+def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, data_chunk,
+                   inv_noise_var_chunk, gain_chunk, amp_prior_std, realisation=True,
+                   omega_n=None, omega_a=None):
+    """Linear operator and right-hand side of the point-source GCR system
+    (ptsrc_sampler.py:17-140).  With ``comm`` (``hydra_amd._dist.Comm``) every rank passes its
+    (freq, time) chunk and the partial Gram / RHS are summed over ranks; only the root's
+    return value is the full system, as in the reference."""
+    myid = comm.Get_rank() if comm is not None else 0
+    bl_i_h, bl_j_h = _tables.baseline_indices(ants, antpairs)
+    nbl = len(antpairs)
+    nf, nt = int(np.size(freq_chunk)), int(np.size(time_chunk))
+    assert tuple(data_chunk.shape) == (nbl, nf, nt)
+    assert tuple(data_chunk.shape) == tuple(inv_noise_var_chunk.shape)
+    factored = isinstance(proj_chunk, FactoredProj)
+    ns = int(proj_chunk.shape[-1])
+    assert tuple(proj_chunk.shape[:3]) == (nbl, nf, nt)
+    ref = data_chunk
+
+    data = _dev.c128(data_chunk)
+    w = _dev.f64(inv_noise_var_chunk)
+    gains = _dev.c128(gain_chunk)
+    sigma = _dev.f64(amp_prior_std)
+    assert gains.shape[1:] == (nf, nt)
+    nant = gains.shape[0]
+    assert max(bl_i_h.max(), bl_j_h.max()) < nant
+    bl_i, bl_j = _dev.i32(bl_i_h), _dev.i32(bl_j_h)
+    st = _dev.stream_ptr()
+    m = nbl * nf * nt
+
+    # fluctuation vectors: injected, or the reference's draws in the reference's order
+    if omega_n is None:
+        omega_n = _draw_omega_n((nbl, nf, nt), realisation)
+    om_n = _dev.c128(omega_n)
+    assert tuple(om_n.shape) == (nbl, nf, nt)
+
+    gg = _dev.empty((nbl, nf, nt), torch.complex128)
+    prior_here = None if comm is not None else sigma
+    if factored:
+        if not (np.array_equal(bl_i_h, proj_chunk.bl_i_host)
+                and np.array_equal(bl_j_h, proj_chunk.bl_j_host)):
+            raise ValueError("antpairs do not match the baselines of the factored operator")
+        _dev.call("hydra_row_factors", _dev.ptr(gains), _dev.ptr(w), _dev.ptr(bl_i),
+                  _dev.ptr(bl_j), nbl, nf, nt, _dev.ptr(gg), _dev.ptr(None), st)
+        A = _timed_gram(lambda: proj_chunk.gram(gains, w, prior_std=prior_here))
+        model = proj_chunk.apply(torch.ones(ns, dtype=torch.float64, device=data.device),
+                                 rowmul=gg)
+    else:
+        R = _dev.c128(proj_chunk).reshape(m, ns)
+        rows = _dev.empty((nbl, nf, nt), torch.complex128)
+        _dev.call("hydra_row_factors", _dev.ptr(gains), _dev.ptr(w), _dev.ptr(bl_i),
+                  _dev.ptr(bl_j), nbl, nf, nt, _dev.ptr(gg), _dev.ptr(rows), st)
+        ws = _dev.workspace(_dev._lib.query("hydra_gram_workspace_bytes", m, ns))
+        A = _dev.empty((ns, ns), torch.float64)
+        _timed_gram(lambda: _dev.call(
+            "hydra_gram", _dev.ptr(R), _dev.ptr(rows), m, ns, _dev.ptr(prior_here),
+            _dev.ptr(None), _dev.ptr(A), _dev.ptr(ws), ws.numel(), st))
+        model = _dev.empty((nbl, nf, nt), torch.complex128)
+        ones = torch.ones(ns, dtype=torch.float64, device=data.device)
+        _dev.call("hydra_apply_R", _dev.ptr(R), m, ns, _dev.ptr(ones), _dev.ptr(gg),
+                  _dev.ptr(model), st)
+
+    # z = conj(gg) ((d - model) N^-1 + omega_n N^-1/2)          ptsrc_sampler.py:104-123
+    z = _dev.empty((nbl, nf, nt), torch.complex128)
+    _dev.call("hydra_rhs_rows", _dev.ptr(data), _dev.ptr(model), _dev.ptr(w), _dev.ptr(om_n),
+              _dev.ptr(gg), m, _dev.ptr(z), st)
+
+    # omega_a is drawn after omega_n, on the root only       ptsrc_sampler.py:137-138
+    om_a = None
+    if myid == 0:
+        if omega_a is None:
+            omega_a = (1.0 if realisation else 0.0) * np.random.randn(ns)
+        om_a = _dev.f64(omega_a)
+    add_here = om_a if comm is None else None
+    if factored:
+        b = proj_chunk.adjoint(z, scale=sigma, add=add_here)
+    else:
+        ws = _dev.workspace(_dev._lib.query("hydra_adjoint_workspace_bytes", m, ns))
+        b = _dev.empty((ns,), torch.float64)
+        _dev.call("hydra_adjoint_R", _dev.ptr(R), m, ns, _dev.ptr(z), _dev.ptr(sigma),
+                  _dev.ptr(add_here), _dev.ptr(b), _dev.ptr(ws), ws.numel(), st)
+
+    if comm is not None:
+        # sum over ranks (comm.Reduce at ptsrc_sampler.py:86,132), then prior + omega_a on root
+        comm.reduce_(A, root=0)
+        comm.reduce_(b, root=0)
+        if myid == 0:
+            _dev.call("hydra_prior_epilogue", _dev.ptr(A), ns, _dev.ptr(sigma), _dev.ptr(None), st)
+            b += om_a
+        else:
+            A = torch.zeros((1, 1), dtype=torch.float64, device=A.device)
+            b = torch.zeros((1,), dtype=torch.float64, device=b.device)
+    return _dev.like(ref, A), _dev.like(ref, b)
+
+
+def apply_proj(proj, x):
+    """Model visibilities ``(proj.reshape(-1, Ns) @ x).reshape(Nbl, Nf, Nt)`` -- the model
+    update of the driver (example.py:974-976) for either operator form."""
+    if isinstance(proj, FactoredProj):
+        return proj.apply(x)
+    nbl, nf, nt, ns = proj.shape
+    R = _dev.c128(proj).reshape(-1, ns)
+    out = _dev.empty((nbl, nf, nt), torch.complex128)
+    _dev.call("hydra_apply_R", _dev.ptr(R), nbl * nf * nt, ns, _dev.ptr(_dev.f64(x)),
+              _dev.ptr(None), _dev.ptr(out), _dev.stream_ptr())
+    return _dev.like(proj, out)

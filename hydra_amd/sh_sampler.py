@@ -1,0 +1,222 @@
+"""
+Spherical-harmonic diffuse head on MI355X -- drop-in for the GCR functions of
+``hydra.sh_sampler`` (reference: hydra/sh_sampler.py).
+
+    vis_proj_operator_no_rot(...) -> (R (Nvis, Nm), autos, ell, m)   sh_sampler.py:65-196
+    construct_rhs_no_rot[_mpi]     b = R^T (N^-1 d + N^-1/2 w_n) + S^-1 a_0 + S^-1/2 w_a   :370-448
+    apply_lhs_no_rot[_mpi]         (R^T N^-1 R + S^-1) a                                    :389-494
+    get_em_ell_idx, alms2healpy, healpy2alms                                               :28-62,199-266
+
+``R^T y`` for complex R and the real parameter vector means Re(R)^T Re(y) + Im(R)^T Im(y)
+= Re(R^H y).  The reference evaluates the left-hand side left-to-right, i.e. it builds the
+(Nm, Nm) Gram on every CG iteration; here the same operator is applied as R^H (N^-1 (R a))
+(two passes over R, HBM bound), and ``lhs_matrix`` builds the Gram once on the FP64 matrix
+cores for callers that iterate many times.  GSM helpers / radiometer_eq / sample_cl of the
+reference module are outside the hot path (they need pygdsm data files) and are not provided.
+"""
+import numpy as np
+import torch
+
+from . import _dev
+from . import vis_simulator as _vs
+
+
+def get_em_ell_idx(lmax):
+    """(ems, ells, idx) of the real parameter vector: all real parts in (m, l) order, then the
+    imaginary parts for m >= 1 (sh_sampler.py:28-62)."""
+    ems, ells = [], []
+    for first_m in (0, 1):
+        for em in range(first_m, lmax + 1):
+            for ell in range(em, lmax + 1):
+                ems.append(em)
+                ells.append(ell)
+    return ems, ells, list(range(len(ems)))
+
+
+def _pairs(names, include_autos, autos_only):
+    cross, autos = [], []
+    for i in names:                       # dict keys double as list indices (sh_sampler.py:137-150)
+        for j in names:
+            if include_autos:
+                if j >= i:
+                    cross.append((names[i], names[j]))
+            elif autos_only:
+                if j == i:
+                    cross.append((names[i], names[j]))
+            else:
+                if j == i:
+                    autos.append((names[i], names[j]))
+                if j > i:
+                    cross.append((names[i], names[j]))
+    return cross, autos
+
+
+def vis_proj_operator_no_rot(freqs, lsts, beams, ant_pos, lmax, nside,
+                             latitude=-0.5361913261514378, include_autos=False,
+                             autos_only=False, ref_freq=100.0, spectral_idx=0.0,
+                             as_torch=False):
+    """Visibility response to each real spherical-harmonic parameter (sh_sampler.py:65-196).
+    ``freqs`` in MHz.  Returns (vis_response_2D (Nbl*Nf*Nt, Nm), autos_2D, ell, m), or without
+    ``autos_2D`` when ``include_autos`` / ``autos_only``.  ``as_torch=True`` keeps the
+    operators on the GPU."""
+    freqs = np.asarray(freqs, dtype=np.float64)
+    lsts = np.atleast_1d(np.asarray(lsts, dtype=np.float64))
+    ell, m = _vs.getlm(lmax)
+    names = list(ant_pos.keys())
+    cross, autos = _pairs(names, include_autos, autos_only)
+    V = _vs.sh_voltages(nside, ant_pos, freqs * 1e6, lsts, beams, latitude)
+    ymap = _vs.sh_mode_maps(lmax, nside, 1.0, packed=True)
+    nm = ymap.shape[1]
+    spec = (freqs / ref_freq) ** spectral_idx
+
+    def project(pairs, scale):
+        bi = np.array([names.index(p[0]) for p in pairs], dtype=np.int32)
+        bj = np.array([names.index(p[1]) for p in pairs], dtype=np.int32)
+        out = _vs.sh_project(V, bi, bj, ymap, scale_f=scale)
+        return out.reshape(len(pairs) * freqs.size * lsts.size, nm)
+
+    resp = project(cross, spec)
+    conv = (lambda t: t) if as_torch else (lambda t: t.cpu().numpy())
+    if not autos_only and not include_autos:
+        au = project(autos, None)          # the reference applies no spectral factor to autos
+        return conv(resp), conv(au), ell, m
+    return conv(resp), ell, m
+
+
+def alms2healpy(alms, lmax):
+    """[Re; Im(m>=1)] -> complex healpy-ordered a_lm (sh_sampler.py:199-232)."""
+    alms = np.asarray(alms)
+    if alms.ndim == 1:
+        split = int((np.size(alms) + (lmax + 1)) / 2)
+        return alms[:split] + 1.0j * np.concatenate((np.zeros(lmax + 1), alms[split:]))
+    if alms.ndim == 2:
+        return np.array([alms2healpy(a, lmax) for a in alms])
+    raise ValueError("alms array must either have shape (Nmodes,) or (Nmaps, Nmodes)")
+
+
+def healpy2alms(healpy_modes):
+    """Complex healpy-ordered a_lm -> [Re; Im(m>=1)] (sh_sampler.py:235-266)."""
+    healpy_modes = np.asarray(healpy_modes)
+    if healpy_modes.ndim == 1:
+        lmax = (-3.0 + np.sqrt(1.0 + 8.0 * healpy_modes.size)) / 2.0   # hp.Alm.getlmax
+        lmax = int(lmax) if lmax == np.floor(lmax) else -1
+        return np.concatenate((healpy_modes.real, healpy_modes.imag[(lmax + 1):]))
+    if healpy_modes.ndim == 2:
+        return np.array([healpy2alms(a) for a in healpy_modes])
+    raise ValueError("Input array must have shape (Nmodes,) or (Nmaps, Nmodes).")
+
+
+def _adjoint(R, z, scale=None, add=None):
+    m, nm = R.shape
+    ws = _dev.workspace(_dev._lib.query("hydra_adjoint_workspace_bytes", m, nm))
+    out = _dev.empty((nm,), torch.float64)
+    _dev.call("hydra_adjoint_R", _dev.ptr(R), m, nm, _dev.ptr(z), _dev.ptr(scale), _dev.ptr(add),
+              _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+    return out
+
+
+def _data_term(data, inv_noise_var, omega_n, R):
+    """Re(R^H (N^-1 d + N^-1/2 w_n))  (sh_sampler.py:376-381, 423-429)."""
+    m = R.shape[0]
+    d = _dev.c128(data).reshape(-1)
+    w = _dev.f64(inv_noise_var).reshape(-1)
+    om = _dev.c128(omega_n).reshape(-1)
+    assert d.numel() == m and w.numel() == m and om.numel() == m
+    z = _dev.empty((m,), torch.complex128)
+    _dev.call("hydra_rhs_rows", _dev.ptr(d), _dev.ptr(None), _dev.ptr(w), _dev.ptr(om),
+              _dev.ptr(None), m, _dev.ptr(z), _dev.stream_ptr())
+    return _adjoint(R, z)
+
+
+def construct_rhs_no_rot(data, inv_noise_var, inv_prior_var, omega_0, omega_1, a_0,
+                         vis_response):
+    """Right-hand side of the SH GCR system (sh_sampler.py:370-386)."""
+    R = _dev.c128(vis_response)
+    ip = _dev.f64(inv_prior_var)
+    term = _data_term(data, inv_noise_var, omega_1, R)
+    rhs = term + (ip * _dev.f64(a_0) + torch.sqrt(ip) * _dev.f64(omega_0))
+    return _dev.like(vis_response, rhs)
+
+
+def construct_rhs_no_rot_mpi(comm, data, inv_noise_var, inv_prior_var, omega_a, omega_n, a_0,
+                             vis_response):
+    """Right-hand side from data split over ranks (sh_sampler.py:405-448): ``omega_a`` is
+    taken from the root (non-root buffers are overwritten, as in the reference), the data
+    terms are summed over ranks, and only the root returns the full vector."""
+    myid = comm.Get_rank() if comm is not None else 0
+    if comm is not None:
+        if myid != 0:
+            omega_a *= 0.0
+        comm.Bcast(omega_a, root=0)
+    R = _dev.c128(vis_response)
+    term = _data_term(data, inv_noise_var, omega_n, R)
+    if comm is not None:
+        comm.reduce_(term, root=0)
+        comm.barrier()
+    if myid == 0:
+        ip = _dev.f64(inv_prior_var)
+        rhs = term + ip * _dev.f64(a_0) + torch.sqrt(ip) * _dev.f64(omega_a)
+        return _dev.like(vis_response, rhs)
+    z = torch.zeros_like(_dev.f64(a_0))
+    return _dev.like(vis_response, z)
+
+
+def _noise_term(a, inv_noise_var, R):
+    """Re(R^H N^-1 R a): one pass for y = R a, one for the adjoint."""
+    m, nm = R.shape
+    w = _dev.f64(inv_noise_var).reshape(-1)
+    assert w.numel() == m
+    y = _dev.empty((m,), torch.complex128)
+    _dev.call("hydra_apply_R", _dev.ptr(R), m, nm, _dev.ptr(a), _dev.ptr(None), _dev.ptr(y),
+              _dev.stream_ptr())
+    _dev.call("hydra_scale_rows", _dev.ptr(y), _dev.ptr(w), m, _dev.ptr(y), _dev.stream_ptr())
+    return _adjoint(R, y)
+
+
+def apply_lhs_no_rot(a_cr, inv_noise_var, inv_prior_var, vis_response):
+    """(R^T N^-1 R + S^-1) a  (sh_sampler.py:389-402)."""
+    R = _dev.c128(vis_response)
+    a = _dev.f64(a_cr)
+    out = _noise_term(a, inv_noise_var, R) + _dev.f64(inv_prior_var) * a
+    return _dev.like(a_cr, out)
+
+
+def apply_lhs_no_rot_mpi(comm, a_cr, inv_noise_var, inv_prior_var, vis_response):
+    """Left-hand side with the data split over ranks (sh_sampler.py:451-494): ``a_cr`` is
+    taken from the root, the noise terms are summed over ranks; the root returns the result,
+    other ranks zeros."""
+    myid = comm.Get_rank() if comm is not None else 0
+    if comm is not None:
+        if myid != 0:
+            a_cr *= 0.0
+        comm.Bcast(a_cr, root=0)
+    R = _dev.c128(vis_response)
+    a = _dev.f64(a_cr)
+    tot = _noise_term(a, inv_noise_var, R)
+    if comm is not None:
+        comm.reduce_(tot, root=0)
+    if myid == 0:
+        return _dev.like(a_cr, tot + _dev.f64(inv_prior_var) * a)
+    return _dev.like(a_cr, torch.zeros_like(a))
+
+
+def lhs_matrix(inv_noise_var, inv_prior_var, vis_response, comm=None):
+    """The SH left-hand-side operator as an explicit matrix
+    A = Re(R^H N^-1 R) + diag(S^-1), built once on the FP64 matrix cores (csrc/gram.hip), so
+    that ``linear_solver.cg(A, b)`` replaces the per-iteration Gram of the reference
+    (sh_sampler.py:393-398).  With ``comm`` the Grams of the ranks' chunks are summed."""
+    R = _dev.c128(vis_response)
+    m, nm = R.shape
+    w = _dev.f64(inv_noise_var).reshape(-1)
+    rows = torch.complex(torch.sqrt(w), torch.zeros_like(w))
+    ws = _dev.workspace(_dev._lib.query("hydra_gram_workspace_bytes", m, nm))
+    A = _dev.empty((nm, nm), torch.float64)
+    ip = _dev.f64(inv_prior_var)
+    _dev.call("hydra_gram", _dev.ptr(R), _dev.ptr(rows), m, nm, _dev.ptr(None),
+              _dev.ptr(ip if comm is None else None), _dev.ptr(A), _dev.ptr(ws), ws.numel(),
+              _dev.stream_ptr())
+    if comm is not None:
+        comm.allreduce_(A)
+        _dev.call("hydra_prior_epilogue", _dev.ptr(A), nm, _dev.ptr(None), _dev.ptr(ip),
+                  _dev.stream_ptr())
+    return _dev.like(vis_response, A)

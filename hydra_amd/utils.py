@@ -1,0 +1,169 @@
+"""
+Utilities used by the GCR hot path and its driver -- drop-in for the corresponding
+functions of ``hydra.utils`` (reference: hydra/utils.py).  ``apply_gains`` runs on the GPU;
+the rest is small host-side set-up (array layout, SEDs, chunk maps, Fourier basis) that the
+reference also does once per run in numpy.
+"""
+import numpy as np
+import torch
+
+from . import _dev, _tables
+
+
+def flatten_vector(v, reduced_idxs=None):
+    """Complex array -> [real block, imaginary block] (utils.py:21-36)."""
+    out = np.concatenate((v.real.flatten(), v.imag.flatten()))
+    return out if reduced_idxs is None else out[reduced_idxs]
+
+
+def reconstruct_vector(v, shape, reduced_idxs=None):
+    """Inverse of ``flatten_vector`` (utils.py:39-60)."""
+    if reduced_idxs is not None:
+        vv = np.zeros(2 * int(np.prod(shape)), dtype=v.dtype)
+        vv[reduced_idxs] = v[:]
+    else:
+        vv = v
+    half = vv.size // 2
+    return (vv[:half] + 1.0j * vv[half:]).reshape(shape)
+
+
+def apply_gains(v, gains, ants, antpairs, perturbation=None, inline=False):
+    """v[k] *= g_i conj(g_j) (1 + x_i + conj(x_j)) for every baseline k = (i, j)
+    (utils.py:63-110).  ``v`` (Nbl,Nf,Nt), ``gains``/``perturbation`` (Nants,Nf,Nt)."""
+    assert v.shape[0] == len(antpairs), (
+        "Input array `v` has shape that is incompatible with `antpairs`")
+    bl_i, bl_j = _tables.baseline_indices(ants, antpairs)
+    nbl, nf, nt = v.shape
+    vd = _dev.c128(v)
+    if _dev.is_torch(v) and not inline and vd.data_ptr() == v.data_ptr():
+        vd = vd.clone()
+    g = _dev.c128(gains)
+    g = g.expand(g.shape[0], nf, nt).contiguous() if tuple(g.shape[1:]) != (nf, nt) else g
+    pert = None
+    if perturbation is not None:
+        pert = _dev.c128(perturbation)
+        pert = pert.expand(pert.shape[0], nf, nt).contiguous()
+    _dev.call("hydra_apply_gains", _dev.ptr(vd), _dev.ptr(g), _dev.ptr(pert),
+              _dev.ptr(_dev.i32(bl_i)), _dev.ptr(_dev.i32(bl_j)), nbl, nf, nt, _dev.stream_ptr())
+    if _dev.is_torch(v):
+        if inline and vd.data_ptr() != v.data_ptr():
+            v.copy_(vd)
+            return v
+        return vd
+    res = vd.cpu().numpy()
+    if inline:
+        v[...] = res
+        return v
+    return res
+
+
+def extract_vis_from_sim(ants, antpairs, sim_vis):
+    """(Nf,Nt,Nants,Nants) -> (Nbl,Nf,Nt) for the requested pairs, un-conjugated order
+    (utils.py:159-198)."""
+    nf, nt, _, _ = sim_vis.shape
+    ants = np.asarray(ants)
+    xp_torch = _dev.is_torch(sim_vis)
+    out = (torch.zeros((len(antpairs), nf, nt), dtype=sim_vis.dtype, device=sim_vis.device)
+           if xp_torch else np.zeros((len(antpairs), nf, nt), dtype=sim_vis.dtype))
+    for k, (a1, a2) in enumerate(antpairs):
+        if a1 > a2:
+            a1, a2 = a2, a1
+        i1 = int(np.where(ants == a1)[0][0])
+        i2 = int(np.where(ants == a2)[0][0])
+        out[k] = sim_vis[:, :, i1, i2]
+    return out
+
+
+def timing_info(fname, iter, task, duration, verbose=True):
+    """Append a timing line to ``fname`` (utils.py:291-310)."""
+    with open(fname, "a") as f:
+        f.write("%05d %7.5f %s\n" % (iter, duration, task))
+        if verbose:
+            print("%s took %3.2f sec" % (task, duration))
+
+
+def freqs_times_for_worker(comm, freqs, times, fchunks, tchunks=1):
+    """(freq idxs, time idxs, worker map) of this rank on the fchunks x tchunks grid
+    (utils.py:313-371)."""
+    myid, nworkers = comm.Get_rank(), comm.Get_size()
+    assert nworkers <= fchunks * tchunks, "There are more workers than time and frequency chunks"
+    grid = np.arange(fchunks * tchunks).reshape((fchunks, tchunks))
+    fsplit = np.array_split(np.arange(np.size(freqs)), fchunks)
+    tsplit = np.array_split(np.arange(np.size(times)), tchunks)
+    worker_map = {}
+    for w in range(nworkers):
+        fi, ti = np.where(grid == w)
+        fi, ti = int(fi[0]), int(ti[0])
+        worker_map[w] = (fi, ti, fsplit[fi], tsplit[ti])
+    fi, ti = worker_map[myid][:2]
+    return fsplit[fi], tsplit[ti], worker_map
+
+
+def build_hex_array(hex_spec=(3, 4), ants_per_row=None, d=14.6):
+    """Antenna dict {id: (x, y, 0.)} of a hexagonally packed array (utils.py:374-419)."""
+    if ants_per_row is None:
+        up = np.arange(hex_spec[0], hex_spec[1] + 1).tolist()
+        ants_per_row = up[:-1] + up[::-1]
+    dy = d * np.sqrt(3) / 2.0
+    ants, k = {}, -1
+    for j, n in enumerate(ants_per_row):
+        y = -0.5 * dy * (len(ants_per_row) - 1) + dy * j
+        x = np.linspace(-d * (n - 1) / 2.0, d * (n - 1) / 2.0, n)
+        for i in range(n):
+            k += 1
+            ants[k] = (x[i], y, 0.0)
+    return ants
+
+
+def get_flux_from_ptsrc_amp(ptsrc_amps, freqs, beta_ptsrc, curv_ptsrc=None, ref_freq=100.0):
+    """Power-law SEDs with optional curvature, shape (Nsrc, Nfreqs) (utils.py:461-501)."""
+    if isinstance(beta_ptsrc, float):
+        beta_ptsrc = beta_ptsrc * np.ones_like(ptsrc_amps)
+    assert ptsrc_amps.size == beta_ptsrc.size
+    if curv_ptsrc is not None and isinstance(curv_ptsrc, float):
+        curv_ptsrc = curv_ptsrc * np.ones_like(ptsrc_amps)
+    if curv_ptsrc is None:
+        curv_ptsrc = np.zeros_like(ptsrc_amps)
+    assert ptsrc_amps.size == curv_ptsrc.size
+    x = freqs / ref_freq
+    spec_idx = beta_ptsrc[:, np.newaxis] + curv_ptsrc[:, np.newaxis] * np.log(x)[np.newaxis, :]
+    return ptsrc_amps[:, np.newaxis] * x[np.newaxis, :] ** spec_idx
+
+
+def partial_fourier_basis_2d(freqs, times, nfreq, ntime, Lfreq, Ltime, freq0=None, time0=None,
+                             shape0=None):
+    """Incomplete 2-D Fourier basis (Nmodes,Nf,Nt) and its wavenumbers (utils.py:625-669)."""
+    time0 = times[0] if time0 is None else time0
+    freq0 = freqs[0] if freq0 is None else freq0
+    nf_norm, nt_norm = (freqs.size, times.size) if shape0 is None else shape0
+    nfreq, ntime = np.atleast_1d(nfreq), np.atleast_1d(ntime)
+    assert nfreq.ndim == 1 and ntime.ndim == 1 and freqs.ndim == 1 and times.ndim == 1
+    t2d, f2d = np.meshgrid(times - time0, freqs - freq0)
+    kfreq = 2.0 * np.pi * nfreq / Lfreq
+    ktime = 2.0 * np.pi * ntime / Ltime
+    phase = (kfreq[:, None, None] * f2d[None, :, :]) + (ktime[:, None, None] * t2d[None, :, :])
+    return np.exp(1.0j * phase) / np.sqrt(nf_norm * nt_norm), kfreq, ktime
+
+
+def partial_fourier_basis_2d_from_nmax(freqs, times, nmaxfreq, nmaxtime, Lfreq, Ltime,
+                                       freq0=None, time0=None, shape0=None,
+                                       positive_only=False):
+    """Fourier basis for wavenumbers -nmax <= n < nmax (or 0 <= n < nmax) (utils.py:672-710)."""
+    if positive_only:
+        nf1, nt1 = np.arange(0, nmaxfreq), np.arange(0, nmaxtime)
+    else:
+        nf1, nt1 = np.arange(-nmaxfreq, nmaxfreq), np.arange(-nmaxtime, nmaxtime)
+    nfreq, ntime = np.meshgrid(nf1, nt1)
+    return partial_fourier_basis_2d(freqs, times, nfreq.flatten(), ntime.flatten(), Lfreq, Ltime,
+                                    freq0, time0, shape0)
+
+
+def status(myid, message, colour=None):
+    """Coloured status line (utils.py:713-739)."""
+    colours = {"r": "\033[91m", "g": "\033[92m", "y": "\033[93m", "b": "\033[94m",
+               "m": "\033[95m", "c": "\033[96m", "bold": "\033[1m", "ul": "\033[4m"}
+    tag = "" if myid is None else "[%d]" % myid
+    if colour is not None:
+        print("%s%s %s%s" % (colours[colour], tag, message, "\033[0m"))
+    else:
+        print("%s %s" % (tag, message))

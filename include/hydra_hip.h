@@ -1,0 +1,235 @@
+/*
+ * hydra_hip.h -- C ABI of libhydra_hip.so: the MI355X (gfx950) implementation of
+ * Hydra's Gaussian-constrained-realisation hot path.
+ *
+ * The reference (HydraRadio/Hydra, pure Python) has no FFI: its boundary for this
+ * path is the module-level Python API of hydra.vis_simulator / ptsrc_sampler /
+ * sh_sampler / linear_solver.  Each entry point below names the reference
+ * expression(s) it replaces (file:line relative to the reference root).  The
+ * Python mirror of that API lives in hydra_amd/ and binds these symbols with
+ * ctypes (hydra_amd/_lib.py); INTEGRATION.md shows the stub a Hydra maintainer
+ * would add.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer unless its name ends in _host;
+ *   - arrays are C-contiguous; complex128 is interleaved (re, im) doubles;
+ *   - `stream` is a hipStream_t passed as void* (0 = default stream); calls are
+ *     asynchronous on it and allocate nothing: scratch comes in through
+ *     (workspace, workspace_bytes), sized by the matching *_workspace_bytes();
+ *   - return value: 0 on success, <0 on error; hydra_last_error() returns a
+ *     thread-local message for the last failure.
+ */
+#ifndef HYDRA_HIP_H
+#define HYDRA_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define HYDRA_OK 0
+#define HYDRA_ERR_ARG (-1)
+#define HYDRA_ERR_WORKSPACE (-2)
+#define HYDRA_ERR_HIP (-3)
+
+/* beam kinds for hydra_voltages() */
+#define HYDRA_BEAM_GAUSS_DIAMETER 0 /* params: [diameter_m]                             */
+#define HYDRA_BEAM_GAUSS_SIGMA 1    /* params: [sigma_rad, ref_freq_hz (0=none), index]  */
+#define HYDRA_BEAM_UNIFORM 2        /* params: unused                                    */
+#define HYDRA_BEAM_VALUES 3         /* beam_vals (Nbeam,Nf,Nt,Ns) power values given     */
+#define HYDRA_BEAM_NPARAMS 4        /* doubles per beam in beam_params                   */
+
+const char* hydra_last_error(void);
+int hydra_abi_version(void);
+
+/* ---- geometry (matvis.coordinates pieces; vis_simulator.py:467,470,247) ---------- */
+
+/* crd_eq (3,Ns) = (cos ra cos dec, sin ra cos dec, sin dec)          vis_simulator.py:467 */
+int hydra_crd_eq(const double* ra, const double* dec, int ns, double* crd_eq, void* stream);
+
+/* eq2tops (Nt,3,3) = eci_to_enu_matrix(lst_t, latitude)              vis_simulator.py:470 */
+int hydra_eq2tops(const double* lsts, int nt, double latitude, double* eq2tops, void* stream);
+
+/* az, za (Nt,Ns) ["uvbeam" convention] and horizon flag tz>0 (uint8) for host-evaluated
+ * beams                                                              vis_simulator.py:233-247 */
+int hydra_az_za(const double* eq2tops, int nt, const double* crd_eq, int ns, double* az,
+                double* za, uint8_t* above, void* stream);
+
+/* ---- response generator ---------------------------------------------------------- */
+
+/* Antenna voltages V (Nf,Nt,Nant,Ns) c128:
+ *   V = sqrt(beam_power(az,za,nu)) * sqrt(0.5 flux) * exp(i 2 pi nu (antpos . s_top) / c),
+ *   zero below the horizon.                          vis_simulator.py:214,233-276,347-359
+ * fluxes (Ns,Nf); beam_idx (Nant) int32 into the Nbeam beams; beam_vals only for
+ * HYDRA_BEAM_VALUES (else NULL).  *bad_flag (device int32, caller-zeroed) is set to 1 if any
+ * beam value is NaN/Inf (the reference raises ValueError, vis_simulator.py:256-257).      */
+int hydra_voltages(const double* antpos, int nant, const double* freqs_hz, int nf,
+                   const double* eq2tops, int nt, const double* crd_eq, int ns,
+                   const double* fluxes, int beam_kind, const double* beam_params, int nbeam,
+                   const int32_t* beam_idx, const double* beam_vals, int force_no_beam_sqrt,
+                   double* V, int32_t* bad_flag, void* stream);
+
+/* Per-source visibilities for a list of antenna pairs:
+ *   R[b,f,t,s] = conj(V[f,t,bl_i[b],s]) * V[f,t,bl_j[b],s]   (Nbl,Nf,Nt,Ns) c128
+ * = vis_sim_per_source's outer product + calc_proj_operator's baseline gather
+ *                                        vis_simulator.py:281-289; ptsrc_sampler.py:209-213 */
+int hydra_response(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                   const int32_t* bl_j, int nbl, double* R, void* stream);
+
+/* Full antenna-antenna cube (Nf,Nt,Nant,Nant,Ns) c128, upper triangle incl. autos, lower
+ * triangle zero -- simulate_vis_per_source's return value       vis_simulator.py:281-289,515 */
+int hydra_vis_cube(const double* V, int nf, int nt, int nant, int ns, double* cube, void* stream);
+
+/* subarr_ant variant: out (Nf,Nt,Nant,Ns) = conj(V[..,a,:]) * V[..,subarr_ant,:]
+ *                                                               vis_simulator.py:290-297 */
+int hydra_vis_subarr(const double* V, int nf, int nt, int nant, int ns, int subarr_ant,
+                     double* out, void* stream);
+
+/* Sum over sources: vis (Nf,Nt,Nant,Nant) c128 upper triangle = sum_s conj(V_i) V_j
+ * (simulate_vis)                                                vis_simulator.py:565-568 */
+int hydra_vis_sum(const double* V, int nf, int nt, int nant, int ns, double* vis, void* stream);
+
+/* ---- GCR operator ---------------------------------------------------------------- */
+
+/* Per-row factors for rows r = (b,f,t) in (Nbl,Nf,Nt) order:
+ *   gg[r]   = g_i conj(g_j)                 (c128)           ptsrc_sampler.py:53-59
+ *   rows[r] = gg[r] * sqrt(inv_noise[r])    (c128)           ptsrc_sampler.py:66-71
+ * gains (Nant,Nf,Nt) c128 or NULL (= 1); inv_noise (Nbl,Nf,Nt) f64 or NULL (= 1).
+ * gg and/or rows may be NULL.                                                          */
+int hydra_row_factors(const double* gains, const double* inv_noise, const int32_t* bl_i,
+                      const int32_t* bl_j, int nbl, int nf, int nt, double* gg, double* rows,
+                      void* stream);
+
+/* Gram of a materialised operator on the FP64 matrix cores:
+ *   G = Re( (diag(rows) R)^H (diag(rows) R) )   (Ns,Ns) f64, full symmetric matrix
+ * R (M,Ns) c128, rows (M) c128 or NULL.  = v_re.T @ v_re + v_im.T @ v_im
+ *                                         ptsrc_sampler.py:62-75; sh_sampler.py:393-398
+ * If prior_std != NULL the epilogue also forms A = I + diag(s) G diag(s)
+ *                                                             ptsrc_sampler.py:91-94
+ * and if add_diag != NULL, A = G + diag(add_diag)             sh_sampler.py:399-401    */
+size_t hydra_gram_workspace_bytes(long long m, int ns);
+int hydra_gram(const double* R, const double* rows, long long m, int ns, const double* prior_std,
+               const double* add_diag, double* G, void* workspace, size_t workspace_bytes,
+               void* stream);
+
+/* The two epilogues of hydra_gram applied in place to a full (Ns,Ns) matrix -- used when raw
+ * Grams of several GPUs are summed first (comm.Reduce, ptsrc_sampler.py:86) and the prior is
+ * applied to the total (ptsrc_sampler.py:91-94).                                          */
+int hydra_prior_epilogue(double* G, int ns, const double* prior_std, const double* add_diag,
+                         void* stream);
+
+/* Same Gram without materialising R (R would be 273 GB at BASELINE config 2):
+ *   R'[(b,f,t),s] = g_i conj(g_j) sqrt(w_bft) conj(V[f,t,i_b,s]) V[f,t,j_b,s].
+ * gains (Nant,Nf,Nt) c128 or NULL; inv_noise (Nbl,Nf,Nt) f64 or NULL.
+ * Tables (built by hydra_amd/_tables.py) group the baselines by antenna block so that one
+ * block pair's voltages fit in LDS: seg (nseg,6) int32 = [i0, ni, j0, nj, row0, nrows];
+ * rowtab (nrows,3) int32 = [LDS row of antenna i, LDS row of antenna j, baseline index b].
+ * Both are passed twice: a host copy (validated before launch) and the device copy.      */
+size_t hydra_gram_fused_workspace_bytes(int nf, int nt, int nbl, int ns);
+int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const double* gains,
+                     const double* inv_noise, int nbl, const int32_t* seg_host,
+                     const int32_t* rowtab_host, const int32_t* seg, const int32_t* rowtab,
+                     int nseg, int nrows, const double* prior_std, const double* add_diag,
+                     double* G, void* workspace, size_t workspace_bytes, void* stream);
+
+/* ---- operator application (RHS, matrix-free LHS, model update) ------------------- */
+
+/* out[r] = rowmul[r] * sum_s R[r,s] x[s]   (M) c128; x (Ns) f64; rowmul (M) c128 or NULL
+ *                       ptsrc_sampler.py:104-106; example.py:974-976,1065; sh_sampler.py:394 */
+int hydra_apply_R(const double* R, long long m, int ns, const double* x, const double* rowmul,
+                  double* out, void* stream);
+
+/* out[s] = scale[s] * sum_r Re( conj(R[r,s]) z[r] ) + add[s]   (Ns) f64
+ * z (M) c128; scale, add (Ns) f64 or NULL.
+ *                       ptsrc_sampler.py:124,138; sh_sampler.py:376-384,393-398           */
+size_t hydra_adjoint_workspace_bytes(long long m, int ns);
+int hydra_adjoint_R(const double* R, long long m, int ns, const double* z, const double* scale,
+                    const double* add, double* out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* Factored forms of the two products above (operator given by V, never materialised):
+ *   out[b,f,t] = gg[b,f,t] * sum_s conj(V[f,t,i_b,s]) V[f,t,j_b,s] x[s]
+ *   out[s]     = scale[s] * sum_{b,f,t} Re( conj(conj(V_i) V_j) z[b,f,t] ) + add[s]       */
+int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                  const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
+                  double* out, void* stream);
+size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns);
+int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                    const int32_t* bl_j, int nbl, const double* z, const double* scale,
+                    const double* add, double* out, void* workspace, size_t workspace_bytes,
+                    void* stream);
+
+/* GCR right-hand-side row term:
+ *   z[r] = conj(gg[r]) * ( (data[r] - model[r]) * w[r] + omega_n[r] * sqrt(w[r]) )
+ * model may be NULL (=0), gg NULL (=1), omega_n NULL (=0).
+ *                                      ptsrc_sampler.py:104-123; sh_sampler.py:423-429 */
+int hydra_rhs_rows(const double* data, const double* model, const double* w,
+                   const double* omega_n, const double* gg, long long m, double* z, void* stream);
+
+/* z[r] = w[r] * y[r]   (complex y, real w) -- the N^-1 in R^H N^-1 R a  sh_sampler.py:470 */
+int hydra_scale_rows(const double* y, const double* w, long long m, double* z, void* stream);
+
+/* ---- solver ---------------------------------------------------------------------- */
+
+/* y = A x, A (N,N) f64 row-major                                  linear_solver.py:431 */
+int hydra_gemv(const double* A, int n, const double* x, double* y, void* stream);
+
+/* Conjugate gradients exactly as linear_solver.cg (linear_solver.py:378-509):
+ * convergence tested BEFORE each iteration, element-wise |r_i| < tol or ||r||_2 < tol.
+ * State (device): x, r, p (N) f64 and `st` = 8 doubles:
+ *   st[0]=rr  st[1]=done(0/1)  st[2]=iterations done  st[3]=max|r| or ||r||  st[4..7] scratch.
+ * hydra_cg_init: given x and r0 = b - A x (caller computes A x): p=r, rr=r.r, test.
+ * hydra_cg_step: given Ap = A p, one fused update (both dot products, x/r/p updates, test).
+ *   Once done==1 a step is a no-op, so the host may enqueue steps ahead of the test.     */
+int hydra_cg_init(int n, const double* b, const double* Ax, double* r, double* p, double* st,
+                  double abs_tol, int use_norm_tol, void* stream);
+int hydra_cg_step(int n, const double* Ap, double* x, double* r, double* p, double* st,
+                  double abs_tol, int use_norm_tol, void* stream);
+
+/* Whole dense solve on the device: x (in: x0, out: solution), A (N,N), b (N).
+ * workspace >= hydra_cg_workspace_bytes(n).  Runs at most maxiters iterations, enqueuing
+ * `check_every` iterations between host reads of the done flag.  *iters_host receives the
+ * iteration count.                                  linear_solver.py:378-509 with Amat given */
+size_t hydra_cg_workspace_bytes(int n);
+int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int maxiters,
+                         double abs_tol, int use_norm_tol, int check_every, int* iters_host,
+                         void* workspace, size_t workspace_bytes, void* stream);
+
+/* Dense fallback: solve A x = b for symmetric positive definite A by blocked Cholesky
+ * (stands for scipy.linalg.solve(A, b, assume_a='her'), example.py:944).  A is overwritten
+ * by its factor; b by x.  Returns 1 if A is not positive definite.                       */
+int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream);
+
+/* ---- spherical-harmonic response (simulate_vis_per_alm) -------------------------- */
+
+/* RING pixel centres: theta, phi (Npix = 12 nside^2)                vis_simulator.py:659 */
+int hydra_healpix_pix2ang(int nside, double* theta, double* phi, void* stream);
+
+/* Ymap (Npix, Ncols) f64, pixel-major: column n holds alm2map(e_n * {1, i}) * (4 pi / Npix)
+ * * amplitude; Ncols = 2 nalm - (lmax+1) in the hydra mode order [Re (nalm); Im without m=0]
+ * when packed != 0, or the reference's raw 2*nalm order when packed == 0.
+ *                                              vis_simulator.py:702-730; sh_sampler.py:127-131 */
+int hydra_sh_mode_maps(int lmax, int nside, double amplitude, int packed, double* ymap,
+                       void* stream);
+
+/* SH response operator on the FP64 matrix cores:
+ *   out[b,f,t,n] = scale_f[f] * sum_p conj(V[f,t,i_b,p]) V[f,t,j_b,p] Ymap[p,n]
+ * (Nbl,Nf,Nt,Nm) c128; V from hydra_voltages with the pixels as unit-flux sources.
+ *                                     vis_simulator.py:702-730; sh_sampler.py:152-168 */
+int hydra_sh_project(const double* V, int nf, int nt, int nant, int npix, const int32_t* bl_i,
+                     const int32_t* bl_j, int nbl, const double* ymap, int nm,
+                     const double* scale_f, double* out, void* stream);
+
+/* ---- gains ------------------------------------------------------------------------ */
+
+/* v[b,f,t] *= g_i conj(g_j) (1 + x_i + conj(x_j)) in place; pert may be NULL
+ *                                                                   utils.py:63-110 */
+int hydra_apply_gains(double* v, const double* gains, const double* pert, const int32_t* bl_i,
+                      const int32_t* bl_j, int nbl, int nf, int nt, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* HYDRA_HIP_H */

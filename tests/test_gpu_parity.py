@@ -1,0 +1,474 @@
+"""
+GPU parity tests: the HIP path (through the C ABI, via the hydra_amd API mirror) against the
+CPU oracle on identical seeded inputs and injected fluctuation vectors, and against the golden
+vectors produced by the reference itself (tests/golden/).
+
+Tolerances (BASELINE.json north_star): operator entries <= 1e-10 relative (FP64); GCR samples
+<= 1e-8 relative.  "Relative" is max|a-b| / max|b| over the array.
+"""
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 1e-10
+SAMPLE_TOL = 1e-8
+LAT = -30.7215 * np.pi / 180.0
+
+
+@pytest.fixture(scope="module")
+def hy():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import hydra_amd
+    return hydra_amd
+
+
+@pytest.fixture(scope="module")
+def orc():
+    from oracle import beams, cg, gcr_ptsrc, gcr_sh, geometry, helpers, response, sphere
+
+    class O:
+        pass
+    o = O()
+    o.beams, o.cg, o.ptsrc, o.sh, o.geometry = beams, cg, gcr_ptsrc, gcr_sh, geometry
+    o.helpers, o.response, o.sphere = helpers, response, sphere
+    return o
+
+
+def _pairs(arr):
+    return [tuple(int(x) for x in p) for p in arr]
+
+
+def _setup(hex_spec=(3, 4), ns=40, nf=3, nt=4, seed=0, wide=False):
+    from oracle import helpers
+    np.random.seed(seed)
+    ant_pos = helpers.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    if wide:
+        ra, dec, amps = helpers.generate_random_ptsrc_catalogue(ns, (0.0, 2 * np.pi),
+                                                                (-0.5 * np.pi, 0.5 * np.pi))
+    else:
+        ra, dec, amps = helpers.generate_random_ptsrc_catalogue(ns, (0.0, 1.0), (-0.6, 0.4))
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    fluxes = helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    return ant_pos, antpairs, ra, dec, freqs, times, fluxes
+
+
+# ------------------------------------------------------------------ response generator
+
+def test_geometry_kernels_match_oracle(hy, orc):
+    import torch
+    from hydra_amd import _dev, vis_simulator as vs
+    rng = np.random.RandomState(1)
+    ra, dec = rng.uniform(0, 2 * np.pi, 300), rng.uniform(-1.5, 1.5, 300)
+    lsts = np.linspace(0.0, 6.0, 7)
+    crd_eq, eq2tops = vs._geometry(ra, dec, lsts, LAT)
+    assert relerr(crd_eq.cpu().numpy(), orc.geometry.point_source_crd_eq(ra, dec)) < 1e-15
+    ref = np.array([orc.geometry.eci_to_enu_matrix(t, LAT) for t in lsts])
+    assert relerr(eq2tops.cpu().numpy(), ref) < 1e-15
+    az = _dev.empty((7, 300), torch.float64)
+    za = _dev.empty((7, 300), torch.float64)
+    up = _dev.empty((7, 300), torch.uint8)
+    _dev.call("hydra_az_za", _dev.ptr(eq2tops), 7, _dev.ptr(crd_eq), 300, _dev.ptr(az),
+              _dev.ptr(za), _dev.ptr(up), _dev.stream_ptr())
+    for t in range(7):
+        top = ref[t] @ orc.geometry.point_source_crd_eq(ra, dec)
+        a, z = orc.geometry.enu_to_az_za(top[0], top[1], "uvbeam")
+        d = np.abs(az[t].cpu().numpy() - a)
+        assert np.max(np.minimum(d, 2 * np.pi - d)) < 1e-9     # az is ill-conditioned at zenith
+        assert np.max(np.abs(za[t].cpu().numpy() - z)) < 1e-12
+        assert np.array_equal(up[t].cpu().numpy().astype(bool), top[2] > 0)
+
+
+def test_per_source_cube_matches_oracle(hy, orc):
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(ns=70, nf=3, nt=4, wide=True)
+    times = np.linspace(0.0, 3.0, 4)
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    ref = orc.response.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times, bo,
+                                               latitude=LAT)
+    got = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
+                                                   bh, latitude=LAT)
+    assert got.shape == ref.shape and got.dtype == np.complex128
+    assert np.count_nonzero(ref) > 0 and np.any(ref == 0)       # sources above and below horizon
+    assert relerr(got, ref) < OP_TOL
+    # lower triangle left at zero, autos populated (vis_simulator.py:281-289)
+    assert np.all(got[:, :, 3, 1] == 0) and np.any(got[:, :, 2, 2] != 0)
+    # sum over sources (simulate_vis) and the subarr_ant variant
+    tot = hy.vis_simulator.simulate_vis(ant_pos, fluxes, ra, dec, freqs * 1e6, times, bh,
+                                        latitude=LAT)
+    assert relerr(tot, ref.sum(axis=-1)) < OP_TOL
+    sub = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
+                                                   bh, latitude=LAT, subarr_ant=2)
+    subref = orc.response.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
+                                                  bo, latitude=LAT, subarr_ant=2)
+    assert relerr(sub, subref) < OP_TOL
+
+
+def test_vis_sim_per_source_single_channel_and_beam_variants(hy, orc):
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(ns=33, nf=2, nt=3)
+    antpos = np.array([ant_pos[k] for k in ant_pos])
+    crd_eq = orc.geometry.point_source_crd_eq(ra, dec)
+    eq2tops = np.array([orc.geometry.eci_to_enu_matrix(t, LAT) for t in times])
+    # one shared beam / fixed-sigma beams with per-antenna widths / uniform beam
+    cases = [
+        ([orc.beams.GaussianBeam(diameter=12.0)], [hy.beams.GaussianBeam(diameter=12.0)]),
+        ([orc.beams.GaussianBeam(sigma=0.2 + 0.01 * k, reference_frequency=1e8,
+                                 spectral_index=-1.0) for k in range(len(ant_pos))],
+         [hy.beams.GaussianBeam(sigma=0.2 + 0.01 * k, reference_frequency=1e8,
+                                spectral_index=-1.0) for k in range(len(ant_pos))]),
+        ([orc.beams.UniformBeam()], [hy.beams.UniformBeam()]),
+    ]
+    for bo, bh in cases:
+        ref = orc.response.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], bo)
+        got = hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], bh)
+        assert got.shape == (times.size, len(ant_pos), len(ant_pos), ra.size)
+        assert relerr(got, ref) < OP_TOL
+    # a beam object without an in-kernel form goes through compute_response on the host
+    class HostBeam(orc.beams.GaussianBeam):
+        pass
+    hb = [HostBeam(diameter=14.0)]
+    ref = orc.response.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], hb)
+    got = hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], hb)
+    assert relerr(got, ref) < OP_TOL
+    # force_no_beam_sqrt
+    ref = orc.response.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
+                                          cases[0][0], force_no_beam_sqrt=True)
+    got = hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
+                                              cases[0][1], force_no_beam_sqrt=True)
+    assert relerr(got, ref) < OP_TOL
+    # error behaviour of the reference: wrong beam count, NaN beam, shape asserts
+    with pytest.raises(ValueError):
+        hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
+                                            [hy.beams.UniformBeam()] * 2)
+
+    class NanBeam:
+        def compute_response(self, *, az_array, za_array, freq_array, **kw):
+            return np.full((1, 1, np.size(freq_array), np.size(za_array)), np.nan)
+    with pytest.raises(ValueError, match="invalid value"):
+        hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
+                                            [NanBeam()])
+    with pytest.raises(AssertionError):
+        hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes[:, :1], ra, dec, freqs * 1e6,
+                                                 times, cases[0][1] * len(ant_pos))
+    with pytest.warns(RuntimeWarning):
+        hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra - 1.0, dec, freqs * 1e6,
+                                                 times, cases[0][1] * len(ant_pos))
+
+
+def test_calc_proj_operator_matches_oracle(hy, orc):
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(ns=50, nf=4, nt=5)
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    ref = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
+    got = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh)
+    assert got.shape == (45, 4, 5, 50)
+    assert relerr(got, ref) < OP_TOL
+    # a pair listed against dict order picks up the zero lower triangle, as in the reference
+    ap2 = [(1, 0)] + antpairs[1:]
+    got2 = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, ap2, freqs, times, bh)
+    ref2 = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, ap2, freqs, times, bo)
+    assert np.all(got2[0] == 0) and relerr(got2, ref2) < OP_TOL
+    # reference smoke test (hydra/tests/test_ptsrc_sampler.py): 3 antennas, 17 sources
+    np.random.seed(3)
+    ant3 = {0: (0.0, 0.0, 0.0), 1: (0.0, 14.0, 0.0), 2: (0.0, 0.0, 14.0)}
+    ap3 = [(0, 1), (0, 2), (1, 2)]
+    lsts = np.linspace(0.0, 3.0, 5)
+    fr = np.linspace(100.0, 200.0, 10)
+    ra3, dec3, amps3 = hy.example.generate_random_ptsrc_catalogue(
+        17, (0.0, 2 * np.pi), (-0.5 * np.pi, 0.5 * np.pi), (-1.0, 2.0))
+    fl3 = hy.utils.get_flux_from_ptsrc_amp(amps3, fr, -2.7)
+    proj = hy.ptsrc_sampler.calc_proj_operator(ra3, dec3, fl3, ant3, ap3, fr, lsts,
+                                               [hy.beams.GaussianBeam(diameter=14.0)] * 3)
+    assert np.all(~np.isnan(proj))
+    ref3 = orc.ptsrc.calc_proj_operator(ra3, dec3, fl3, ant3, ap3, fr, lsts,
+                                        [orc.beams.GaussianBeam(diameter=14.0)] * 3)
+    assert relerr(proj, ref3) < OP_TOL
+    data = (proj.reshape((-1, 17)) @ np.ones(17)).reshape(3, 10, 5)
+    A, b = hy.ptsrc_sampler.precompute_mpi(
+        comm=None, ants=list(ant3.keys()), antpairs=ap3, freq_chunk=fr, time_chunk=lsts,
+        proj_chunk=proj, data_chunk=data, inv_noise_var_chunk=np.ones(data.shape),
+        gain_chunk=(1.1 + 1.0j) * np.ones((3, 10, 5)), amp_prior_std=0.1 * np.ones(17),
+        realisation=True)
+    assert np.all(~np.isnan(A)) and np.all(~np.isnan(b))
+
+
+# ------------------------------------------------------------------ GCR operator and RHS
+
+@pytest.mark.parametrize("name", ["ptsrc_small.npz", "ptsrc_c1like.npz"])
+def test_precompute_matches_reference_golden(hy, name):
+    g = load_golden(name)
+    ap = _pairs(g["antpairs"])
+    nf, nt = g["data"].shape[1:]
+    A, b = hy.ptsrc_sampler.precompute_mpi(
+        None, g["ants"], ap, np.arange(nf), np.arange(nt), g["proj"], g["data"], g["inv_noise"],
+        g["gains"], g["prior"], realisation=True, omega_n=g["omega_n"], omega_a=g["omega_a"])
+    assert relerr(A, g["A"]) < OP_TOL
+    assert relerr(b, g["b"]) < OP_TOL
+    assert np.array_equal(A, A.T)
+    # drawing omega from the global RNG in the reference's order reproduces the reference
+    np.random.seed(int(g["seed"]))
+    A2, b2 = hy.ptsrc_sampler.precompute_mpi(
+        None, g["ants"], ap, np.arange(nf), np.arange(nt), g["proj"], g["data"], g["inv_noise"],
+        g["gains"], g["prior"], realisation=True)
+    assert relerr(b2, g["b"]) < OP_TOL
+    A0, b0 = hy.ptsrc_sampler.precompute_mpi(
+        None, g["ants"], ap, np.arange(nf), np.arange(nt), g["proj"], g["data"], g["inv_noise"],
+        g["gains"], g["prior"], realisation=False)
+    assert relerr(A0, g["A0"]) < OP_TOL and relerr(b0, g["b0"]) < OP_TOL
+    # samples: CG and the dense fallback against the reference's dense solve of its own system
+    import scipy.linalg
+    xref = scipy.linalg.solve(g["A"], g["b"], assume_a="her")
+    x = hy.linear_solver.cg(A, b, maxiters=1000, abs_tol=1e-10)
+    assert relerr(x, xref) < SAMPLE_TOL
+    assert np.linalg.norm(g["A"] @ x - g["b"]) / np.linalg.norm(g["b"]) < SAMPLE_TOL
+    xd = hy.linear_solver.solve_dense(A, b)
+    assert relerr(xd, xref) < SAMPLE_TOL
+
+
+def _gcr_inputs(nbl, nant, nf, nt, ns, seed, uniform_noise=False):
+    rng = np.random.RandomState(seed)
+    gains = (1.0 + 1.0j) + 0.05 * (rng.randn(nant, 1, 1) + 1j * rng.randn(nant, 1, 1)) \
+        + 0.01 * (rng.randn(nant, nf, nt) + 1j * rng.randn(nant, nf, nt))
+    inv_noise = np.full((nbl, nf, nt), 400.0) if uniform_noise else \
+        rng.uniform(100.0, 900.0, (nbl, nf, nt))
+    if not uniform_noise:
+        inv_noise[rng.randint(nbl), :, 0] = 0.0
+    prior = rng.uniform(0.05, 0.2, ns)
+    om_n = (rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)) / np.sqrt(2)
+    om_a = rng.randn(ns)
+    return gains, inv_noise, prior, om_n, om_a
+
+
+@pytest.mark.parametrize("hex_spec,ns,nf,nt", [((3, 4), 100, 4, 5), ((4, 7), 150, 2, 3),
+                                               ((5, 9), 200, 2, 2)])
+def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, nf, nt):
+    """End to end on the simulator's own operator: fused (factored) path == materialised HIP
+    path == oracle, for one-segment (10, 37 antennas) and multi-segment (61 antennas) tables;
+    Ns not a multiple of the 128 tile, odd row counts."""
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(hex_spec, ns, nf, nt, seed=5)
+    nant, nbl = len(ant_pos), len(antpairs)
+    ants = np.array(list(ant_pos.keys()))
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    proj_ref = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
+    gains, inv_noise, prior, om_n, om_a = _gcr_inputs(nbl, nant, nf, nt, ns, seed=7)
+    truth = 1.0 + 0.1 * np.random.RandomState(8).randn(ns)
+    data = orc.helpers.apply_gains((proj_ref.reshape(-1, ns) @ truth).reshape(nbl, nf, nt),
+                                   gains, ants, antpairs)
+    data = data + 0.05 * om_n[::-1]
+    A_ref, b_ref = orc.ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
+                                        omega_n=om_n, omega_a=om_a)
+    fac = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh,
+                                              materialize=False)
+    assert fac.shape == proj_ref.shape
+    if nant > 37:
+        assert fac.seg_host.shape[0] > 1
+    R = fac.materialize().cpu().numpy()
+    assert relerr(R, proj_ref) < OP_TOL
+    args = (None, ants, antpairs, freqs, times)
+    kw = dict(data_chunk=data, inv_noise_var_chunk=inv_noise, gain_chunk=gains,
+              amp_prior_std=prior, omega_n=om_n, omega_a=om_a)
+    A_f, b_f = hy.ptsrc_sampler.precompute_mpi(*args, proj_chunk=fac, **kw)
+    A_m, b_m = hy.ptsrc_sampler.precompute_mpi(*args, proj_chunk=R, **kw)
+    for A, b in ((A_f, b_f), (A_m, b_m)):
+        assert relerr(A, A_ref) < OP_TOL
+        assert relerr(b, b_ref) < OP_TOL
+    # model update (example.py:974-976) in both forms
+    mod_ref = (proj_ref.reshape(-1, ns) @ truth).reshape(nbl, nf, nt)
+    assert relerr(hy.ptsrc_sampler.apply_proj(R, truth), mod_ref) < OP_TOL
+    assert relerr(hy.ptsrc_sampler.apply_proj(fac, truth).cpu().numpy(), mod_ref) < OP_TOL
+    # the sample
+    x_ref = orc.ptsrc.dense_solve(A_ref, b_ref)
+    x = hy.linear_solver.cg(A_f, b_f, maxiters=2000, abs_tol=1e-9)
+    assert relerr(x, x_ref) < SAMPLE_TOL
+    assert np.linalg.norm(A_ref @ x - b_ref) / np.linalg.norm(b_ref) < SAMPLE_TOL
+
+
+def test_gram_kernel_shapes_and_symmetry(hy, orc):
+    """hydra_gram alone on random (asymmetric) operators: tile edges (Ns = 1, 127, 128, 129,
+    300), row counts that do not divide the split, with and without row factors."""
+    import torch
+    from hydra_amd import _dev
+    rng = np.random.RandomState(11)
+    for m, ns, with_rows in [(5, 1, True), (1000, 127, True), (777, 128, False),
+                             (4099, 129, True), (2500, 300, True)]:
+        R = rng.randn(m, ns) + 1j * rng.randn(m, ns)
+        rows = rng.randn(m) + 1j * rng.randn(m) if with_rows else None
+        Rp = R * rows[:, None] if with_rows else R
+        ref = Rp.real.T @ Rp.real + Rp.imag.T @ Rp.imag
+        Rd = _dev.c128(R)
+        rd = _dev.c128(rows) if with_rows else None
+        ws = _dev.workspace(_dev._lib.query("hydra_gram_workspace_bytes", m, ns))
+        G = _dev.empty((ns, ns), torch.float64)
+        _dev.call("hydra_gram", _dev.ptr(Rd), _dev.ptr(rd), m, ns, _dev.ptr(None), _dev.ptr(None),
+                  _dev.ptr(G), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+        Gh = G.cpu().numpy()
+        assert relerr(Gh, ref) < 1e-12, (m, ns)
+        assert np.array_equal(Gh, Gh.T)
+        # bitwise reproducible (fixed-order slab reduction, no atomics)
+        G2 = _dev.empty((ns, ns), torch.float64)
+        _dev.call("hydra_gram", _dev.ptr(Rd), _dev.ptr(rd), m, ns, _dev.ptr(None), _dev.ptr(None),
+                  _dev.ptr(G2), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+        assert torch.equal(G, G2)
+
+
+# ------------------------------------------------------------------ solver
+
+def test_cg_matches_reference_golden(hy, orc):
+    g = load_golden("cg.npz")
+    # hydra/tests/test_linear_solver.py:9-54 on the GPU path
+    n = 401
+    A1 = np.eye(n)
+    x1 = hy.linear_solver.cg(A1, A1 @ g["xtrue"], maxiters=1000, abs_tol=1e-8)
+    assert np.allclose(g["xtrue"], x1)
+    x2, it2 = hy.linear_solver.cg(g["A2"], g["b2"], maxiters=1000, abs_tol=1e-8,
+                                  return_iters=True)
+    assert np.allclose(g["xtrue"], x2)
+    assert relerr(x2, g["x2"]) < SAMPLE_TOL
+    _, it_ref = orc.cg.cg(g["A2"], g["b2"], return_iters=True)
+    assert abs(it2 - it_ref) <= 1
+    x2a = hy.linear_solver.cg(None, g["b2"], maxiters=1000, abs_tol=1e-8,
+                              linear_op=lambda v: g["A2"] @ v)
+    assert np.allclose(g["xtrue"], x2a) and np.allclose(x2, x2a)
+    assert relerr(hy.linear_solver.cg(g["A2"], g["b2"], abs_tol=1e-6, use_norm_tol=True),
+                  g["x2n"]) < 1e-6
+    # maxiters is honoured exactly, no convergence flag is raised
+    x5 = hy.linear_solver.cg(g["A2"], g["b2"], maxiters=5)
+    assert relerr(x5, g["x2_5"]) < 1e-10
+    x3 = hy.linear_solver.cg(g["A3"], g["b3"], abs_tol=1e-10, x0=g["x03"].copy())
+    assert relerr(x3, g["x3"]) < SAMPLE_TOL
+    with pytest.raises(AssertionError):
+        hy.linear_solver.cg(g["A3"], g["b3"], x0=np.zeros(5))
+    # already-converged start: zero iterations, x0 returned
+    xs = np.linalg.solve(g["A3"], g["b3"])
+    xc, itc = hy.linear_solver.cg(g["A3"], g["b3"], abs_tol=1e-6, x0=xs.copy(), return_iters=True)
+    assert itc == 0 and np.array_equal(xc, xs)
+    # torch (device-resident) operator path
+    import torch
+    Ad = torch.as_tensor(g["A3"]).cuda()
+    xt = hy.linear_solver.cg(None, torch.as_tensor(g["b3"]).cuda(), abs_tol=1e-10,
+                             linear_op=lambda v: Ad @ v)
+    assert xt.is_cuda and relerr(xt.cpu().numpy(), xs) < SAMPLE_TOL
+
+
+def test_dense_fallback_matches_scipy(hy):
+    import scipy.linalg
+    rng = np.random.RandomState(2)
+    for n in (1, 31, 32, 33, 100, 257):
+        B = rng.randn(2 * n + 3, n)
+        A = np.eye(n) + 0.1 * (B.T @ B)
+        b = rng.randn(n)
+        x = hy.linear_solver.solve_dense(A, b)
+        xref = scipy.linalg.solve(A, b, assume_a="her")
+        assert relerr(x, xref) < 1e-10, n
+    with pytest.raises(np.linalg.LinAlgError):
+        hy.linear_solver.solve_dense(-np.eye(4), np.ones(4))
+
+
+# ------------------------------------------------------------------ gains helper
+
+def test_apply_gains_matches_reference_golden(hy):
+    g = load_golden("gains.npz")
+    ap = _pairs(g["antpairs"])
+    out = hy.utils.apply_gains(g["v"], g["g"], g["ants"], ap)
+    assert relerr(out, g["out_plain"]) < 1e-14
+    out = hy.utils.apply_gains(g["v"], g["g"], g["ants"], ap, perturbation=g["pert"])
+    assert relerr(out, g["out_pert"]) < 1e-14
+    v = g["v"].copy()
+    r = hy.utils.apply_gains(v, g["g"], g["ants"], ap, inline=True)
+    assert r is v and relerr(v, g["out_plain"]) < 1e-14
+    assert np.array_equal(hy.utils.extract_vis_from_sim(g["ants"], ap, g["simvis"]),
+                          g["extracted"])
+
+
+# ------------------------------------------------------------------ spherical harmonics
+
+def test_healpix_and_mode_maps_match_oracle(hy, orc):
+    for nside in (1, 2, 8, 16):
+        th, ph = hy.vis_simulator.healpix_pixel_coords(nside)
+        tr, pr = orc.sphere.pix2ang_ring(nside, np.arange(12 * nside * nside))
+        assert np.max(np.abs(th.cpu().numpy() - tr)) < 1e-14
+        assert np.max(np.abs(ph.cpu().numpy() - pr)) < 1e-14
+    for lmax, nside in [(0, 1), (3, 2), (10, 8), (40, 8)]:
+        npix = 12 * nside * nside
+        ref = orc.sphere.unit_mode_maps(lmax, nside) * (4 * np.pi / npix)
+        got = hy.vis_simulator.sh_mode_maps(lmax, nside, 1.0, packed=False).cpu().numpy()
+        assert got.shape == (npix, ref.shape[0])
+        assert relerr(got.T, ref) < 1e-11
+        nalm = ref.shape[0] // 2
+        keep = np.concatenate((np.arange(nalm), np.arange(nalm + lmax + 1, 2 * nalm)))
+        gp = hy.vis_simulator.sh_mode_maps(lmax, nside, 2.0, packed=True).cpu().numpy()
+        assert relerr(gp.T, 2.0 * ref[keep]) < 1e-11
+    ell, m = hy.vis_simulator.getlm(7)
+    er, mr = orc.sphere.getlm(7)
+    assert np.array_equal(ell, er) and np.array_equal(m, mr)
+
+
+def test_sh_response_operator_matches_oracle(hy, orc):
+    # hydra/tests/test_sh_sampler.py:21-67 geometry; lmax/nside reduced for the CPU oracle
+    ant_pos = {0: (0.0, 0.0, 0.0), 1: (0.0, 14.0, 0.0), 2: (0.0, 0.0, 14.0), 3: (20.0, 5.0, 1.0)}
+    lsts = np.linspace(0.0, 3.0, 3)
+    freqs = np.linspace(100.0, 200.0, 2)
+    lmax, nside = 5, 4
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    pr, ar, ell_r, m_r = orc.sh.vis_proj_operator_no_rot(freqs, lsts, bo, ant_pos, lmax, nside,
+                                                         spectral_idx=-2.5)
+    pg, ag, ell, m = hy.sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside,
+                                                            spectral_idx=-2.5)
+    ems, ells, idx = hy.sh_sampler.get_em_ell_idx(lmax)
+    assert pg.shape == (6 * freqs.size * lsts.size, len(ems)) and ag.shape[0] == 4 * 6
+    assert np.array_equal(ell, ell_r) and np.array_equal(m, m_r)
+    assert relerr(pg, pr) < OP_TOL and relerr(ag, ar) < OP_TOL
+    assert not np.allclose(pg.imag, 0)
+    # include_autos / autos_only variants return 3-tuples
+    p2, _, _ = hy.sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside,
+                                                      include_autos=True)
+    r2, _, _ = orc.sh.vis_proj_operator_no_rot(freqs, lsts, bo, ant_pos, lmax, nside,
+                                               include_autos=True)
+    assert p2.shape == r2.shape and relerr(p2, r2) < OP_TOL
+    # the raw simulate_vis_per_alm cube (2*nalm modes, zero lower triangle)
+    e3, m3, cube = hy.vis_simulator.simulate_vis_per_alm(lmax, nside, ant_pos, freqs * 1e6, lsts, bh,
+                                                         latitude=-0.5361913261514378)
+    e4, m4, cube_r = orc.response.simulate_vis_per_alm(lmax, nside, ant_pos, freqs * 1e6, lsts, bo,
+                                                       latitude=-0.5361913261514378)
+    assert cube.shape == cube_r.shape and relerr(cube, cube_r) < OP_TOL
+
+
+def test_sh_algebra_matches_reference_golden(hy, orc):
+    g = load_golden("sh_algebra.npz")
+    lmax = int(g["lmax"])
+    ems, ells, idx = hy.sh_sampler.get_em_ell_idx(lmax)
+    assert np.array_equal(ems, g["ems"]) and np.array_equal(ells, g["ells"])
+    rhs = hy.sh_sampler.construct_rhs_no_rot(g["data"].flatten(), g["inv_noise"].flatten(),
+                                             g["inv_prior"], g["omega_a"], g["omega_n"].flatten(),
+                                             g["a0"], g["R"])
+    assert relerr(rhs, g["rhs"]) < OP_TOL
+    rhs2 = hy.sh_sampler.construct_rhs_no_rot_mpi(None, g["data"], g["inv_noise"], g["inv_prior"],
+                                                  g["omega_a"].copy(), g["omega_n"], g["a0"], g["R"])
+    assert relerr(rhs2, g["rhs_mpi"]) < OP_TOL
+    lhs = hy.sh_sampler.apply_lhs_no_rot(g["acr"], g["inv_noise"].flatten(), g["inv_prior"], g["R"])
+    assert relerr(lhs, g["lhs"]) < OP_TOL
+    lhs2 = hy.sh_sampler.apply_lhs_no_rot_mpi(None, g["acr"].copy(), g["inv_noise"],
+                                              g["inv_prior"], g["R"])
+    assert relerr(lhs2, g["lhs_mpi"]) < OP_TOL
+    assert np.array_equal(hy.sh_sampler.alms2healpy(g["packed"], lmax), g["hp_modes"])
+    assert np.array_equal(hy.sh_sampler.healpy2alms(g["hp_modes"]), g["packed"])
+    # explicit operator (Gram once) reproduces the matrix-free apply
+    A = hy.sh_sampler.lhs_matrix(g["inv_noise"], g["inv_prior"], g["R"])
+    assert relerr(A @ g["acr"], g["lhs"]) < OP_TOL
+    # the GCR sample: CG with the matrix-free operator (the driver's call, example.py:1045-1052)
+    # and with the explicit matrix, against the reference's own CG solution
+    x = hy.linear_solver.cg(
+        Amat=None, bvec=rhs2, maxiters=1000, abs_tol=1e-8, use_norm_tol=False, x0=g["a0"].copy(),
+        linear_op=lambda v: hy.sh_sampler.apply_lhs_no_rot_mpi(None, v, g["inv_noise"],
+                                                               g["inv_prior"], g["R"]))
+    assert relerr(x, g["x_cg"]) < SAMPLE_TOL
+    xA = hy.linear_solver.cg(A, rhs2, maxiters=1000, abs_tol=1e-8, x0=g["a0"].copy())
+    assert relerr(xA, g["x_cg"]) < SAMPLE_TOL
