@@ -115,6 +115,9 @@ def main():
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cg-tol", type=float, default=1e-8)
+    ap.add_argument("--solver", default="dense", choices=["dense", "cg"],
+                    help="dense = blocked Cholesky (the reference's default for this head, "
+                         "example.py:944); cg = linear_solver.cg")
     args = ap.parse_args()
 
     import torch
@@ -164,9 +167,11 @@ def main():
         om_a = torch.randn(ns, dtype=torch.float64, device=dev, generator=gen)
         A, b = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
                                             inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
-        if rank == 0:
+        if rank == 0 and args.solver == "cg":
             x, iters = hy.linear_solver.cg(A, b, maxiters=1000, abs_tol=args.cg_tol,
                                            return_iters=True)
+        elif rank == 0:
+            x, iters = hy.linear_solver.solve_dense(A, b), 0
         else:
             x, iters = torch.zeros(ns, dtype=torch.float64, device=dev), 0
         if comm is not None:
@@ -218,7 +223,8 @@ def main():
             "workload": (f"BASELINE config {args.config}: ptsrc GCR, hex{hex_spec} = {nant} antennas "
                          f"/ {nbl} baselines, {ns} sources, {nf} freqs x {nt} times, complex128, "
                          f"factored operator (R never materialised)"),
-            "rows_M": m_all, "cg_abs_tol": args.cg_tol, "cg_iters_last": int(iters),
+            "rows_M": m_all, "solver": args.solver, "cg_abs_tol": args.cg_tol,
+            "cg_iters_last": int(iters),
             "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
         },
         "gram_tflops_whole_job": world * achieved,

@@ -75,6 +75,18 @@ def declared_symbols():
     return sorted(prototypes().keys())
 
 
+def _load_hip_runtime():
+    """libhydra_hip.so is linked WITHOUT its own HIP runtime (-no-hip-rt): a process must hold
+    exactly one libamdhip64, and PyTorch-ROCm ships its own.  Import torch first and make its
+    runtime's symbols global so ours resolve against it."""
+    import torch
+    rt = os.path.join(os.path.dirname(torch.__file__), "lib", "libamdhip64.so")
+    if os.path.exists(rt):
+        ctypes.CDLL(rt, mode=ctypes.RTLD_GLOBAL)
+    else:                                   # a torch build that uses the system ROCm
+        ctypes.CDLL("libamdhip64.so", mode=ctypes.RTLD_GLOBAL)
+
+
 def load():
     """Load the library and bind every declared entry point (cached)."""
     global _lib
@@ -84,6 +96,7 @@ def load():
         raise RuntimeError(
             f"{LIBRARY} not found: the HIP library has not been built. hydra_amd has no CPU "
             "fallback; run `make -C hydra_amd/csrc` (or __graft_entry__.build()) first.")
+    _load_hip_runtime()
     lib = ctypes.CDLL(LIBRARY)
     for name, (restype, argtypes, _) in prototypes().items():
         try:

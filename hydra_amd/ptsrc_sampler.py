@@ -76,8 +76,9 @@ class FactoredProj:
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
         out = _dev.empty((nbl, nf, nt), torch.complex128)
+        xd = _dev.f64(x)
         _dev.call("hydra_apply_V", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(self.bl_i),
-                  _dev.ptr(self.bl_j), nbl, _dev.ptr(_dev.f64(x)), _dev.ptr(rowmul),
+                  _dev.ptr(self.bl_j), nbl, _dev.ptr(xd), _dev.ptr(rowmul),
                   _dev.ptr(out), _dev.stream_ptr())
         return out
 
@@ -245,6 +246,7 @@ def apply_proj(proj, x):
     nbl, nf, nt, ns = proj.shape
     R = _dev.c128(proj).reshape(-1, ns)
     out = _dev.empty((nbl, nf, nt), torch.complex128)
-    _dev.call("hydra_apply_R", _dev.ptr(R), nbl * nf * nt, ns, _dev.ptr(_dev.f64(x)),
+    xd = _dev.f64(x)
+    _dev.call("hydra_apply_R", _dev.ptr(R), nbl * nf * nt, ns, _dev.ptr(xd),
               _dev.ptr(None), _dev.ptr(out), _dev.stream_ptr())
     return _dev.like(proj, out)

@@ -43,8 +43,9 @@ def apply_gains(v, gains, ants, antpairs, perturbation=None, inline=False):
     if perturbation is not None:
         pert = _dev.c128(perturbation)
         pert = pert.expand(pert.shape[0], nf, nt).contiguous()
-    _dev.call("hydra_apply_gains", _dev.ptr(vd), _dev.ptr(g), _dev.ptr(pert),
-              _dev.ptr(_dev.i32(bl_i)), _dev.ptr(_dev.i32(bl_j)), nbl, nf, nt, _dev.stream_ptr())
+    bi_d, bj_d = _dev.i32(bl_i), _dev.i32(bl_j)       # keep alive across the launch
+    _dev.call("hydra_apply_gains", _dev.ptr(vd), _dev.ptr(g), _dev.ptr(pert), _dev.ptr(bi_d),
+              _dev.ptr(bj_d), nbl, nf, nt, _dev.stream_ptr())
     if _dev.is_torch(v):
         if inline and vd.data_ptr() != v.data_ptr():
             v.copy_(vd)
