@@ -76,7 +76,6 @@ struct RowsProducer {
   int ca[4], cb[4];
   double ma[4], mb[4];
   int kr;
-  const f64x2* rp;
   f64x2 c;
 
   __device__ __forceinline__ void init(const f64x2* R_, const f64x2* rows_, long long k_end_,
@@ -91,45 +90,56 @@ struct RowsProducer {
       cb[i] = EDGE ? min(b, ns - 1) : b;
     }
   }
-  // select the row of this lane for the k-step starting at k0
-  __device__ __forceinline__ void begin(long long k0) {
+  f64x2 xa[4], xb[4];
+  // loads of the k-step starting at k0 (row clamped and zero-weighted past the end)
+  __device__ __forceinline__ void issue(long long k0) {
     long long row = k0 + kr;
     bool valid = row < k_end;
     if (!valid) row = k_end - 1;
     c = f64x2{1.0, 0.0};
     if (rows) c = rows[row];
     if (!valid) c = f64x2{0.0, 0.0};
-    rp = R + (size_t)row * ns;
+    const f64x2* rp = R + (size_t)row * ns;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) { xa[g] = rp[ca[g]]; xb[g] = rp[cb[g]]; }
   }
-  __device__ __forceinline__ void produce(int g, Frag& f) const {
-    f64x2 y = cmul(c, rp[ca[g]]);
-    f64x2 z = cmul(c, rp[cb[g]]);
-    if (EDGE) { y.x *= ma[g]; y.y *= ma[g]; z.x *= mb[g]; z.y *= mb[g]; }
-    f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
+  __device__ __forceinline__ void finish(Frag& f) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f64x2 y = cmul(c, xa[g]);
+      f64x2 z = cmul(c, xb[g]);
+      if (EDGE) { y.x *= ma[g]; y.y *= ma[g]; z.x *= mb[g]; z.y *= mb[g]; }
+      f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
+    }
   }
 };
 
-// 32 MFMAs of the current k-step interleaved with the production of the next step's
-// operands, so loads / VALU of step k+1 sit in the shadow of the matrix pipe.
+// Software pipeline of one wave.  FP64 VALU work does not hide under an f64 MFMA on gfx950
+// (both run on the SIMD's FP64 lanes: tools/mfma_peak.hip measures +18 cycles for the first
+// v_fma_f64 placed after an MFMA and ~4.5 for each further one), and with one wave per SIMD a
+// wait on LDS / memory idles the matrix pipe.  So each k-step is cut into three phases kept
+// apart with sched_barrier: (1) issue the loads of step k+1, (2) 32 back-to-back MFMAs of step
+// k, which cover the load latency, (3) one batch of VALU turning the loaded values into the
+// operands of step k+1.
 template <class P>
 __device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long long k_end,
                                               f64x4 (&acc)[4][4]) {
-  Frag cur, nxt;
-  prod.begin(k_begin);
-#pragma unroll
-  for (int g = 0; g < 4; ++g) prod.produce(g, cur);
+  Frag cur;
+  prod.issue(k_begin);
+  prod.finish(cur);
   for (long long k0 = k_begin; k0 < k_end; k0 += 4) {
-    long long kn = (k0 + 4 < k_end) ? k0 + 4 : k0;  // last step re-produces itself (unused)
-    prod.begin(kn);
+    prod.issue(k0 + 4);  // past the end: the producer clamps the row and yields zeros
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      prod.produce(g, nxt);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[g][ni] = mfma(cur.are[g], cur.bre[ni], acc[g][ni]);
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
     }
-    cur = nxt;
+    __builtin_amdgcn_sched_barrier(0);
+    prod.finish(cur);
+    __builtin_amdgcn_sched_barrier(0);
   }
 }
 
@@ -239,49 +249,65 @@ static void gram_plan(long long nunits, int ns, int* ntiles, int* nsplit, long l
 
 // ------------------------------------------------------------------ fused (factored) form
 
-// sqrtw_t[ft][b] = sqrt(inv_noise[b][ft]) (or 1): contiguous per (f,t) slice for LDS staging
+// w_t[ft][b] = inv_noise[b][ft] (or 1): contiguous per (f,t) slice for LDS staging
 __global__ void __launch_bounds__(256)
 sqrtw_transpose_kernel(const double* __restrict__ w, int nbl, int nft, double* __restrict__ out) {
   size_t n = (size_t)nbl * nft;
   for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n;
        o += (size_t)gridDim.x * blockDim.x) {
     size_t ft = o / nbl, b = o % nbl;
-    out[o] = w ? sqrt(w[b * (size_t)nft + ft]) : 1.0;
+    out[o] = w ? w[b * (size_t)nft + ft] : 1.0;
   }
 }
 
 struct FusedProducer {
   const f64x2* s_u;
-  const double* s_sw;
+  const double* s_w;
   const uint32_t* s_info;
   int nrows, kr, offA, offB;
-  const f64x2* pi;
-  const f64x2* pj;
-  double sw;
+  uint32_t info_next;   // packed LDS rows of the step after the one being issued
+  double w_next, w;
+  f64x2 ai[4], aj[4], bi[4], bj[4];
 
-  __device__ __forceinline__ void begin(long long k0) {
-    int r = (int)k0 + kr;
+  __device__ __forceinline__ void prefetch_info(int k0) {
+    int r = k0 + kr;
     bool valid = r < nrows;
-    uint32_t info = s_info[valid ? r : 0];
-    sw = valid ? s_sw[r] : 0.0;
-    pi = s_u + (info & 0xffffu) * 256;
-    pj = s_u + (info >> 16) * 256;
+    info_next = s_info[valid ? r : 0];
+    w_next = valid ? s_w[r] : 0.0;
   }
-  // R'[r,s] = sqrt(w_r) conj(u_i,s) u_j,s with u_a = conj(g_a) v_a staged in LDS
-  __device__ __forceinline__ void produce(int g, Frag& f) const {
-    f64x2 ui = pi[offA + g * 16], uj = pj[offA + g * 16];
-    ui.x *= sw; ui.y *= sw;
-    f64x2 y = cmul_conj(ui, uj);
-    f64x2 wi = pi[offB + g * 16], wj = pj[offB + g * 16];
-    wi.x *= sw; wi.y *= sw;
-    f64x2 z = cmul_conj(wi, wj);
-    f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
+  __device__ __forceinline__ void start(int k0) { prefetch_info(k0); }
+  // LDS reads of the k-step whose row info was prefetched; then prefetch the next step's info
+  __device__ __forceinline__ void issue(long long k0) {
+    const f64x2* pi = s_u + (info_next & 0xffffu) * 256;
+    const f64x2* pj = s_u + (info_next >> 16) * 256;
+    w = w_next;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      ai[g] = pi[offA + g * 16]; aj[g] = pj[offA + g * 16];
+      bi[g] = pi[offB + g * 16]; bj[g] = pj[offB + g * 16];
+    }
+    prefetch_info((int)k0 + 4);
+  }
+  // R'[r,s] = conj(u_i,s) u_j,s with u_a = conj(g_a) v_a staged in LDS; the noise weight w_r
+  // goes wholly on the A side (sum_r w_r t_r[s] t_r[s'] needs it once)
+  __device__ __forceinline__ void finish(Frag& f) const {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f64x2 ui = ai[g];
+      ui.x *= w; ui.y *= w;
+      f64x2 y = cmul_conj(ui, aj[g]);
+      f64x2 z = cmul_conj(bi[g], bj[g]);
+      f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
+    }
   }
 };
 
 // LDS: u[nrows_lds][256] complex (cols 0..127: A side = row-tile sources; 128..255: B side)
 //      info[max_rows] uint32 (ldsrow_i | ldsrow_j << 16), sw[max_rows] f64
-__global__ void __launch_bounds__(256, 1)
+// launch bound of 2 waves/SIMD caps the kernel at 256 registers so that hipcc keeps the MFMA
+// accumulators in ArchVGPRs: on gfx950 an f64 MFMA whose C/D operand sits in AGPRs issues at
+// about half rate (tools/mfma_peak.hip: 138 vs 64 cycles per v_mfma_f64_16x16x4_f64)
+__global__ void __launch_bounds__(256, 2)
 gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                   const f64x2* __restrict__ gains, const double* __restrict__ sqrtw_t, int nbl,
                   const int32_t* __restrict__ seg, int nseg, const int32_t* __restrict__ rowtab,
@@ -342,8 +368,9 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
       __syncthreads();
 
       FusedProducer prod;
-      prod.s_u = s_u; prod.s_sw = s_sw; prod.s_info = s_info;
+      prod.s_u = s_u; prod.s_w = s_sw; prod.s_info = s_info;
       prod.nrows = nrows; prod.kr = kr; prod.offA = offA; prod.offB = offB;
+      prod.start(0);
       mfma_pipeline(prod, 0, nrows, acc);
     }
   }
