@@ -15,7 +15,7 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hydra_hip.h")
-LIBRARY = os.path.join(_HERE, "libhydra_hip.so")
+LIBRARY = os.environ.get("HYDRA_HIP_LIBRARY", os.path.join(_HERE, "libhydra_hip.so"))
 
 _CTYPE = {
     "int": ctypes.c_int,

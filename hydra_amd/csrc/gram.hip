@@ -24,6 +24,17 @@
 
 namespace hydra {
 
+#ifdef HYDRA_GRAM_STAMPS
+// Diagnostic build only (make stamps): cycle shares of the fused kernel's phases, summed by
+// wave 0 of workgroup 0.  [0] LDS fill, [1] load issue, [2] MFMA burst, [3] VALU batch,
+// [4] k-steps, [5] shader cycles total, [6] 100 MHz ticks total.  Never built into the product.
+__device__ unsigned long long g_stamps[8];
+#define STAMP(var)                                                                       \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
+
 constexpr int TS = 128;            // workgroup tile edge
 constexpr int TILE_ELEMS = TS * TS;
 
@@ -127,8 +138,17 @@ __device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long l
   Frag cur;
   prod.issue(k_begin);
   prod.finish(cur);
+#ifdef HYDRA_GRAM_STAMPS
+  unsigned long long t0, t1, t2, t3, s_issue = 0, s_mfma = 0, s_valu = 0, s_steps = 0;
+#endif
   for (long long k0 = k_begin; k0 < k_end; k0 += 4) {
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(t0)
+#endif
     prod.issue(k0 + 4);  // past the end: the producer clamps the row and yields zeros
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(t1)
+#endif
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -138,9 +158,21 @@ __device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long l
       for (int ni = 0; ni < 4; ++ni) acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
     }
     __builtin_amdgcn_sched_barrier(0);
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(t2)
+#endif
     prod.finish(cur);
     __builtin_amdgcn_sched_barrier(0);
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(t3)
+    s_issue += t1 - t0; s_mfma += t2 - t1; s_valu += t3 - t2; s_steps += 1;
+#endif
   }
+#ifdef HYDRA_GRAM_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_stamps[1] += s_issue; g_stamps[2] += s_mfma; g_stamps[3] += s_valu; g_stamps[4] += s_steps;
+  }
+#endif
 }
 
 template <bool EDGE>
@@ -327,6 +359,9 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   int ft_begin = split * ft_per_split;
   int ft_end = ft_begin + ft_per_split;
   if (ft_end > nft) ft_end = nft;
+#ifdef HYDRA_GRAM_STAMPS
+  unsigned long long k_c0 = __builtin_amdgcn_s_memtime(), k_r0 = __builtin_amdgcn_s_memrealtime();
+#endif
 
   f64x4 acc[4][4];
 #pragma unroll
@@ -347,18 +382,25 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
       const int32_t* sd = seg + 6 * sg;
       int i0 = sd[0], ni = sd[1], j0 = sd[2], nj = sd[3], row0 = sd[4], nrows = sd[5];
       int nload = (j0 == i0) ? ni : ni + nj;
+#ifdef HYDRA_GRAM_STAMPS
+      unsigned long long f0, f1;
+      STAMP(f0)
+#endif
       __syncthreads();  // previous segment fully consumed
-      for (int a = 0; a < nload; ++a) {
-        int ant = (a < ni) ? i0 + a : j0 + (a - ni);
-        f64x2 u = {0.0, 0.0};
-        if (scol_ok) {
-          u = vft[(size_t)ant * ns + scol];
-          if (gains) {
-            f64x2 g = gains[(size_t)ant * nft + ft];
-            u = cmul_conj(g, u);  // conj(g_a) v_a
-          }
+      // stage u_a = conj(g_a) v_a: 8 antennas per pass so 8 global loads are in flight per lane
+      for (int a0 = 0; a0 < nload; a0 += 8) {
+        f64x2 u[8], g[8];
+#pragma unroll
+        for (int q = 0; q < 8; ++q) {
+          int a = a0 + q;
+          int ant = (a < ni) ? i0 + a : j0 + (a - ni);
+          bool ok = scol_ok && a < nload;
+          u[q] = ok ? vft[(size_t)ant * ns + scol] : f64x2{0.0, 0.0};
+          g[q] = (ok && gains) ? gains[(size_t)ant * nft + ft] : f64x2{1.0, 0.0};
         }
-        s_u[a * 256 + tid] = u;
+#pragma unroll
+        for (int q = 0; q < 8; ++q)
+          if (a0 + q < nload) s_u[(a0 + q) * 256 + tid] = cmul_conj(g[q], u[q]);
       }
       for (int r = tid; r < nrows; r += 256) {
         const int32_t* rt = rowtab + 3 * (size_t)(row0 + r);
@@ -366,6 +408,10 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
         s_sw[r] = sqrtw_t[(size_t)ft * nbl + rt[2]];
       }
       __syncthreads();
+#ifdef HYDRA_GRAM_STAMPS
+      STAMP(f1)
+      if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[0] += f1 - f0;
+#endif
 
       FusedProducer prod;
       prod.s_u = s_u; prod.s_w = s_sw; prod.s_info = s_info;
@@ -375,11 +421,28 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     }
   }
   store_tile(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, wr, wc, lane);
+#ifdef HYDRA_GRAM_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_stamps[5] += __builtin_amdgcn_s_memtime() - k_c0;
+    g_stamps[6] += __builtin_amdgcn_s_memrealtime() - k_r0;
+  }
+#endif
 }
 
 }  // namespace hydra
 
 using namespace hydra;
+
+#ifdef HYDRA_GRAM_STAMPS
+extern "C" int hydra_debug_stamps(unsigned long long* out_host, int reset) {
+  if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -3;
+  if (reset) {
+    unsigned long long z[8] = {0, 0, 0, 0, 0, 0, 0, 0};
+    if (hipMemcpyToSymbol(HIP_SYMBOL(g_stamps), z, sizeof(z)) != hipSuccess) return -3;
+  }
+  return 0;
+}
+#endif
 
 extern "C" {
 
