@@ -64,6 +64,16 @@ def synth_inputs(hex_spec, ns, nf, nt):
                 fluxes=fluxes, g0=g0, x_true=x_true, sigma_noise=0.05, prior=0.1 * np.ones(ns))
 
 
+def pmc_traffic(config):
+    """HBM bytes per launch of the dominant kernel from the committed rocprofv3 --pmc passes of
+    this same command (profiles/pmc_traffic.json; tools/gpu_check.sh collects them), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "pmc_traffic.json")) as fh:
+            return json.load(fh)[config]["traffic_bytes"]
+    except (OSError, KeyError, ValueError):
+        return None
+
+
 def cpu_baseline(inp, nf_s, nt_s, full_rows):
     """Time the oracle (numpy/scipy restatement of the reference) on an (nf_s x nt_s) slice of
     the workload and scale linearly in the number of visibility rows."""
@@ -231,7 +241,8 @@ def main():
         "sample_rel_residual": resid,
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc_traffic(args.config) if world == 1 else None,
             "kernel": "gram_fused_kernel", "ms_per_launch": gram_ms,
             "flops_per_launch": gram_flops,
         },
