@@ -199,7 +199,12 @@ def cg_mpi(comm_groups, Amat_block, bvec_block, vec_size, block_map, maxiters=10
     myrow, mycol = block_map[myid]
     A = _dev.f64(Amat_block)
     r = _dev.f64(bvec_block).clone()
-    p = r.clone()
+    # The reference's r_block / pvec_block start as views of bvec_block (linear_solver.py:300-301).
+    # Diagonal ranks rebind them every iteration; off-diagonal ranks only ever write pvec_block
+    # in place (:324-325), so there r_block IS the p received from the diagonal, and that is
+    # what their convergence test (:309) sees.  Keep that aliasing: without it off-diagonal
+    # ranks never report convergence and the iteration runs on into 0/0.
+    p = r if myrow != mycol else r.clone()
     x = torch.zeros_like(r)
     y = torch.empty_like(r)
     niter = 0

@@ -229,6 +229,49 @@ int hydra_sh_project(const double* V, int nf, int nt, int nant, int npix, const 
 int hydra_apply_gains(double* v, const double* gains, const double* pert, const int32_t* bl_i,
                       const int32_t* bl_j, int nbl, int nf, int nt, void* stream);
 
+/* ---- linearised gain head (hydra/gain_sampler.py; BASELINE config 4) ---------------
+ * The reference's sparse (Nbl x Nant) projectors A_real (+1,+1) / A_imag (+1,-1)
+ * (gain_sampler.py:51-78) are passed as a CSR adjacency antenna -> baselines:
+ *   adj_ptr (Nant+1), adj_b (nadj) baseline index, adj_o (nadj) the baseline's other antenna,
+ *   adj_role (nadj) 0 if the antenna is the first of the pair, 1 if the second.
+ * adj_ptr is passed twice (host copy validated before launch, device copy used by the kernel).
+ * Gain-parameter vectors x are (nvec, 2*Nant*Nmodes) f64: real parts then imaginary parts,
+ * each (Nant, Nmodes) -- the layout of gain_sampler.py:257-258,294.  nft = Nf*Nt.          */
+
+/* W[b,f,t] = |model_vis|^2 * inv_noise (inv_noise NULL = 1): all that survives between A and
+ * A^H in apply_operator_mpi                                      gain_sampler.py:278-284 */
+int hydra_gain_weights(const double* model_vis, const double* inv_noise, long long m, double* W,
+                       void* stream);
+
+/* g[v,a,f,t] = sum_m Fbasis[m,f,t] * pspec_sqrt[m] (xre[v,a,m] + i xim[v,a,m])  (c128)
+ *                                                                gain_sampler.py:257-272 */
+int hydra_gain_basis_fwd(const double* x, int nvec, int nant, int nmodes, int nft,
+                         const double* Fbasis, const double* pspec_sqrt, double* g, void* stream);
+
+/* y = A^H N^-1 A g for nvec antenna fields at once (one pass over W per 8 vectors):
+ *   y[v,a] = g[v,a] sum_{b in adj(a)} W[b] + conj(sum_{b in adj(a)} W[b] g[v,other(b)])
+ *                                                                gain_sampler.py:278-284 */
+int hydra_gain_pairs(const double* g, int nvec, int nant, int nft, const double* W, int nbl,
+                     const int32_t* adj_ptr_host, const int32_t* adj_ptr, const int32_t* adj_b,
+                     const int32_t* adj_o, int nadj, double* y, void* stream);
+
+/* apply_proj: out[b,f,t] = (x_i + conj(x_j)) model_vis[b,f,t]    gain_sampler.py:81-106 */
+int hydra_gain_proj(const double* x, const int32_t* bl_i, const int32_t* bl_j, int nbl,
+                    const double* model_vis, int nft, double* out, void* stream);
+
+/* apply_proj_conj: y[a] = sum_{b: a first} v conj(mv) + sum_{b: a second} conj(v conj(mv))
+ *                                                                gain_sampler.py:109-142 */
+int hydra_gain_proj_conj(const double* v, const double* model_vis, int nant, int nft,
+                         const int32_t* adj_ptr_host, const int32_t* adj_ptr,
+                         const int32_t* adj_b, const int32_t* adj_role, int nadj, double* y,
+                         void* stream);
+
+/* out[v] = [Re; Im] of pspec_sqrt[m] sum_{f,t} conj(Fbasis[m,f,t]) y[v,a,f,t]  (+ add[v] if
+ * add != NULL; add has the layout of out)            gain_sampler.py:213-220,286-301 */
+int hydra_gain_basis_adj(const double* y, int nvec, int nant, int nmodes, int nft,
+                         const double* Fbasis, const double* pspec_sqrt, const double* add,
+                         double* out, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

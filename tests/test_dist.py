@@ -1,0 +1,59 @@
+"""
+Multi-process tests of the N > 1 path (one process per rank, gloo on 127.0.0.1):
+hydra_amd._dist.Comm (the mpi4py subset the reference uses: ptsrc_sampler.py:86,132;
+sh_sampler.py:420-485; linear_solver.py:48-367) and the block layout on the CPU; the
+frequency-sharded point-source system and cg_mpi with every rank on the one GPU of the box.
+"""
+import os
+import socket
+import subprocess
+import sys
+
+import pytest
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _run(case, nproc, timeout=300):
+    import glob
+    import tempfile
+    logdir = tempfile.mkdtemp(prefix=f"hydra_dist_{case}_")
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env["OMP_NUM_THREADS"] = "1"
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}",
+           "--master-addr", "127.0.0.1", "--master-port", str(_free_port()),
+           os.path.join(HERE, "dist_worker.py"), case, logdir]
+    res = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=timeout)
+    errs = "\n".join(f"--- {os.path.basename(f)}\n{open(f).read()}"
+                     for f in sorted(glob.glob(os.path.join(logdir, "*.err"))))
+    assert res.returncode == 0, errs + "\n" + res.stdout[-1500:] + "\n" + res.stderr[-1500:]
+    assert res.stdout.count(f"ok: {case}") == nproc, res.stdout[-2000:]
+
+
+def test_comm_collectives_world2():
+    _run("comm", 2)
+
+
+def test_comm_collectives_world3():
+    _run("comm", 3)
+
+
+def test_block_layout_world4():
+    _run("blocks", 4)
+
+
+@pytest.mark.gpu
+def test_freq_sharded_ptsrc_system_world2():
+    _run("ptsrc", 2)
+
+
+@pytest.mark.gpu
+def test_cg_mpi_world4():
+    _run("cgmpi", 4)

@@ -475,3 +475,82 @@ def test_sh_algebra_matches_reference_golden(hy, orc):
     assert relerr(x, g["x_cg"]) < SAMPLE_TOL
     xA = hy.linear_solver.cg(A, rhs2, maxiters=1000, abs_tol=1e-8, x0=g["a0"].copy())
     assert relerr(xA, g["x_cg"]) < SAMPLE_TOL
+
+
+# ------------------------------------------------------------------ gain head (config 4)
+
+def test_gain_head_matches_reference_golden(hy):
+    """proj_operator / apply_proj / apply_proj_conj / apply_operator_mpi / construct_rhs_mpi
+    against the outputs of the reference's own functions (tests/golden/gain.npz)."""
+    from oracle import gcr_gain
+    gs = hy.gain_sampler
+    g = load_golden("gain.npz")
+    ap = _pairs(g["antpairs"])
+    A_real, A_imag = gs.proj_operator(g["ants"], ap)
+    assert np.array_equal(np.asarray(A_real.todense()), g["A_real"])
+    assert np.array_equal(np.asarray(A_imag.todense()), g["A_imag"])
+    assert relerr(gs.apply_proj(g["x"], A_real, A_imag, g["mv"]), g["vproj"]) < OP_TOL
+    assert relerr(gs.apply_proj_conj(g["vv"], A_real, A_imag, g["mv"], g["x"].shape),
+                  g["gconj"]) < OP_TOL
+    # projectors handed over as plain dense arrays (not made by proj_operator) work too
+    assert relerr(gs.apply_proj(g["x"], g["A_real"], g["A_imag"], g["mv"]), g["vproj"]) < OP_TOL
+    opx = gs.apply_operator_mpi(None, g["xvec"], g["inv_noise"], g["ps_sqrt"], A_real, A_imag,
+                                g["mv"], g["Fb"])
+    assert relerr(opx, g["opx"]) < OP_TOL
+    # the reference's own draws (seeded inside construct_rhs_mpi) ...
+    b = gs.construct_rhs_mpi(None, g["resid"], g["inv_noise"], g["ps_sqrt"], A_real, A_imag,
+                             g["mv"], g["Fb"], realisation=True, seed=int(g["seed"]))
+    assert relerr(b, g["bvec"]) < OP_TOL
+    # ... and the same vectors injected
+    nant, nmodes = g["x"].shape[0], g["Fb"].shape[0]
+    om_y, om_r = gcr_gain.draw_gain_omegas(int(g["seed"]), nant, nmodes, g["resid"].shape)
+    b2 = gs.construct_rhs_mpi(None, g["resid"], g["inv_noise"], g["ps_sqrt"], A_real, A_imag,
+                              g["mv"], g["Fb"], omega_y=om_y, omega_r=om_r)
+    assert relerr(b2, g["bvec"]) < OP_TOL
+
+
+@pytest.mark.parametrize("hex_spec,nf,nt,nmax,nvec", [((3, 4), 7, 5, 2, 3), ((4, 7), 16, 12, 3, 9)])
+def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, nt, nmax, nvec):
+    """GainOperator (device-resident weights, batched vectors) against the oracle's restatement
+    of apply_operator_mpi, with subsets of baselines and non-uniform noise; then a CG solve of
+    the gain system through linear_solver.cg(linear_op=...) as the driver does
+    (example.py:719-728), checked against a dense solve of the oracle operator."""
+    from oracle import gcr_gain
+    gs = hy.gain_sampler
+    rng = np.random.RandomState(42)
+    ant_pos = orc.helpers.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    antpairs = [p for k, p in enumerate(antpairs) if k % 7 != 3]          # some baselines flagged out
+    nbl = len(antpairs)
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    Fb, kf, kt = orc.helpers.partial_fourier_basis_2d_from_nmax(
+        freqs, times, nmax, nmax, freqs[-1] - freqs[0], times[-1] - times[0])
+    nmodes = Fb.shape[0]
+    mv = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    w = 50.0 + 400.0 * rng.rand(nbl, nf, nt)
+    ps = 0.05 + 0.1 * rng.rand(nmodes)
+    A_real, A_imag = gs.proj_operator(ants, antpairs)
+    i1, i2 = gcr_gain.bl_indices(ants, antpairs)
+    n = 2 * nant * nmodes
+    X = rng.randn(nvec, n)
+    op = gs.GainOperator(w, ps, A_real, A_imag, mv, Fb)
+    Y = op.apply(X)
+    for v in range(nvec):
+        ref = gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)
+        assert relerr(Y[v], ref) < OP_TOL
+    assert relerr(op.apply(X[0]), Y[0]) < 1e-14                             # single-vector path
+    assert relerr(gs.apply_operator_mpi(None, X[1], w, ps, A_real, A_imag, mv, Fb), Y[1]) < 1e-14
+
+    resid = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    om_y, om_r = gcr_gain.draw_gain_omegas(5, nant, nmodes, resid.shape)
+    b_ref = gcr_gain.construct_rhs(resid, w, ps, i1, i2, mv, Fb, om_y, om_r)
+    b = gs.construct_rhs_mpi(None, resid, w, ps, A_real, A_imag, mv, Fb, seed=5)
+    assert relerr(b, b_ref) < OP_TOL
+    x = hy.linear_solver.cg(None, b, maxiters=2000, abs_tol=1e-11, use_norm_tol=True,
+                            linear_op=op.apply)
+    Aref = np.column_stack([gcr_gain.apply_operator(e, w, ps, i1, i2, mv, Fb) for e in np.eye(n)])
+    x_ref = np.linalg.solve(Aref, b_ref)
+    assert relerr(x, x_ref) < SAMPLE_TOL
