@@ -134,18 +134,18 @@ struct RowsProducer {
 // operands of step k+1.
 template <class P>
 __device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long long k_end,
-                                              f64x4 (&acc)[4][4]) {
+                                              f64x4 (&acc)[4][4], int kstride = 4) {
   Frag cur;
   prod.issue(k_begin);
   prod.finish(cur);
 #ifdef HYDRA_GRAM_STAMPS
   unsigned long long t0, t1, t2, t3, s_issue = 0, s_mfma = 0, s_valu = 0, s_steps = 0;
 #endif
-  for (long long k0 = k_begin; k0 < k_end; k0 += 4) {
+  for (long long k0 = k_begin; k0 < k_end; k0 += kstride) {
 #ifdef HYDRA_GRAM_STAMPS
     STAMP(t0)
 #endif
-    prod.issue(k0 + 4);  // past the end: the producer clamps the row and yields zeros
+    prod.issue(k0 + kstride);  // past the end: the producer clamps the row and yields zeros
 #ifdef HYDRA_GRAM_STAMPS
     STAMP(t1)
 #endif
@@ -296,7 +296,7 @@ struct FusedProducer {
   const f64x2* s_u;
   const double* s_w;
   const uint32_t* s_info;
-  int nrows, kr, offA, offB;
+  int nrows, kr, offA, offB, kstride;
   uint32_t info_next;   // packed LDS rows of the step after the one being issued
   double w_next, w;
   f64x2 ai[4], aj[4], bi[4], bj[4];
@@ -318,7 +318,7 @@ struct FusedProducer {
       ai[g] = pi[offA + g * 16]; aj[g] = pj[offA + g * 16];
       bi[g] = pi[offB + g * 16]; bj[g] = pj[offB + g * 16];
     }
-    prefetch_info((int)k0 + 4);
+    prefetch_info((int)k0 + kstride);
   }
   // R'[r,s] = conj(u_i,s) u_j,s with u_a = conj(g_a) v_a staged in LDS; the noise weight w_r
   // goes wholly on the A side (sum_r w_r t_r[s] t_r[s'] needs it once)
@@ -336,10 +336,17 @@ struct FusedProducer {
 
 // LDS: u[nrows_lds][256] complex (cols 0..127: A side = row-tile sources; 128..255: B side)
 //      info[max_rows] uint32 (ldsrow_i | ldsrow_j << 16), sw[max_rows] f64
-// launch bound of 2 waves/SIMD caps the kernel at 256 registers so that hipcc keeps the MFMA
-// accumulators in ArchVGPRs: on gfx950 an f64 MFMA whose C/D operand sits in AGPRs issues at
-// about half rate (tools/mfma_peak.hip: 138 vs 64 cycles per v_mfma_f64_16x16x4_f64)
-__global__ void __launch_bounds__(256, 2)
+// The register cap of 256 (2 waves per SIMD) makes hipcc keep the MFMA accumulators in
+// ArchVGPRs: on gfx950 an f64 MFMA whose C/D operand sits in AGPRs issues at about half rate
+// (tools/mfma_peak.hip: 138 vs 64 cycles per v_mfma_f64_16x16x4_f64).
+//
+// NG = number of wave groups of 4 waves.  With many antennas the LDS staging leaves room for
+// one workgroup per CU only; NG = 2 then puts two waves on every SIMD that share the staged
+// voltages and take alternate k-steps of the same 128x128 tile, so one wave's LDS reads,
+// waits and VALU batch run under the other's MFMA burst.  Group 1 hands its accumulators to
+// group 0 through LDS at the end (fixed order: group 0 + group 1).
+template <int NG>
+__global__ void __launch_bounds__(256 * NG, 2 / NG)
 gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                   const f64x2* __restrict__ gains, const double* __restrict__ sqrtw_t, int nbl,
                   const int32_t* __restrict__ seg, int nseg, const int32_t* __restrict__ rowtab,
@@ -349,12 +356,13 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   f64x2* s_u = reinterpret_cast<f64x2*>(smem);
   double* s_sw = reinterpret_cast<double*>(smem + (size_t)max_lds_rows * 256 * 16);
   uint32_t* s_info = reinterpret_cast<uint32_t*>(s_sw + max_seg_rows);
+  constexpr int NTHREADS = 256 * NG;
 
   int tile, split;
   block_work(blockIdx.x, ntiles, &tile, &split);
   int ti, tj;
   tile_of(tile, &ti, &tj);
-  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
   int wr = wave >> 1, wc = wave & 1;
   int ft_begin = split * ft_per_split;
   int ft_end = ft_begin + ft_per_split;
@@ -369,8 +377,9 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  // column this thread stages into LDS
-  int scol = (tid < 128) ? ti * TS + tid : tj * TS + (tid - 128);
+  // column this thread stages into LDS (each group stages every NG-th antenna)
+  int scid = tid & 255;
+  int scol = (scid < 128) ? ti * TS + scid : tj * TS + (scid - 128);
   bool scol_ok = scol < ns;
   const int kr = lane >> 4;
   const int offA = wr * 64 + (lane & 15);
@@ -388,11 +397,11 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 #endif
       __syncthreads();  // previous segment fully consumed
       // stage u_a = conj(g_a) v_a: 8 antennas per pass so 8 global loads are in flight per lane
-      for (int a0 = 0; a0 < nload; a0 += 8) {
+      for (int a0 = grp; a0 < nload; a0 += 8 * NG) {
         f64x2 u[8], g[8];
 #pragma unroll
         for (int q = 0; q < 8; ++q) {
-          int a = a0 + q;
+          int a = a0 + q * NG;
           int ant = (a < ni) ? i0 + a : j0 + (a - ni);
           bool ok = scol_ok && a < nload;
           u[q] = ok ? vft[(size_t)ant * ns + scol] : f64x2{0.0, 0.0};
@@ -400,9 +409,9 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
         }
 #pragma unroll
         for (int q = 0; q < 8; ++q)
-          if (a0 + q < nload) s_u[(a0 + q) * 256 + tid] = cmul_conj(g[q], u[q]);
+          if (a0 + q * NG < nload) s_u[(a0 + q * NG) * 256 + scid] = cmul_conj(g[q], u[q]);
       }
-      for (int r = tid; r < nrows; r += 256) {
+      for (int r = tid; r < nrows; r += NTHREADS) {
         const int32_t* rt = rowtab + 3 * (size_t)(row0 + r);
         s_info[r] = (uint32_t)rt[0] | ((uint32_t)rt[1] << 16);
         s_sw[r] = sqrtw_t[(size_t)ft * nbl + rt[2]];
@@ -416,11 +425,35 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
       FusedProducer prod;
       prod.s_u = s_u; prod.s_w = s_sw; prod.s_info = s_info;
       prod.nrows = nrows; prod.kr = kr; prod.offA = offA; prod.offB = offB;
-      prod.start(0);
-      mfma_pipeline(prod, 0, nrows, acc);
+      prod.kstride = 4 * NG;
+      prod.start(4 * grp);
+      mfma_pipeline(prod, 4 * grp, nrows, acc, 4 * NG);
     }
   }
-  store_tile(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, wr, wc, lane);
+  if (NG == 2) {
+    // group 1 -> LDS -> group 0; slot index keeps the 256 lanes of a group on consecutive words
+    double* s_red = reinterpret_cast<double*>(smem);
+    __syncthreads();
+    if (grp == 1) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) s_red[((i * 4 + j) * 4 + g) * 256 + scid] = acc[i][j][g];
+    }
+    __syncthreads();
+    if (grp == 0) {
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][j][g] += s_red[((i * 4 + j) * 4 + g) * 256 + scid];
+    }
+  }
+  if (grp == 0)
+    store_tile(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, wr, wc, lane);
 #ifdef HYDRA_GRAM_STAMPS
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     g_stamps[5] += __builtin_amdgcn_s_memtime() - k_c0;
@@ -547,14 +580,23 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
   hipStream_t st = as_stream(stream);
   sqrtw_transpose_kernel<<<2048, 256, 0, st>>>(inv_noise, nbl, nft, sqrtw_t);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused(sqrtw)");
-  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(&gram_fused_kernel),
-                                     hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+  // two wave groups per workgroup when LDS leaves room for a single workgroup per CU
+  bool two_groups = lds > 80 * 1024;
+  if (two_groups) lds = std::max<size_t>(lds, (size_t)TILE_ELEMS * sizeof(double));
+  const void* kfn = two_groups ? reinterpret_cast<const void*>(&gram_fused_kernel<2>)
+                               : reinterpret_cast<const void*>(&gram_fused_kernel<1>);
+  hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
   if (e != hipSuccess)
     return fail(HYDRA_ERR_HIP, "hydra_gram_fused: cannot reserve %zu bytes of LDS: %s", lds,
                 hipGetErrorString(e));
-  gram_fused_kernel<<<ntiles * nsplit, 256, lds, st>>>(
-      reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
-      sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
+  if (two_groups)
+    gram_fused_kernel<2><<<ntiles * nsplit, 512, lds, st>>>(
+        reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
+        sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
+  else
+    gram_fused_kernel<1><<<ntiles * nsplit, 256, lds, st>>>(
+        reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
+        sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused");
   gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused(finish)");
