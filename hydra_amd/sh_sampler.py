@@ -54,11 +54,12 @@ def _pairs(names, include_autos, autos_only):
 def vis_proj_operator_no_rot(freqs, lsts, beams, ant_pos, lmax, nside,
                              latitude=-0.5361913261514378, include_autos=False,
                              autos_only=False, ref_freq=100.0, spectral_idx=0.0,
-                             as_torch=False):
+                             as_torch=False, cross_only=False):
     """Visibility response to each real spherical-harmonic parameter (sh_sampler.py:65-196).
     ``freqs`` in MHz.  Returns (vis_response_2D (Nbl*Nf*Nt, Nm), autos_2D, ell, m), or without
     ``autos_2D`` when ``include_autos`` / ``autos_only``.  ``as_torch=True`` keeps the
-    operators on the GPU."""
+    operators on the GPU; ``cross_only=True`` skips the auto-correlation operator and returns
+    (vis_response_2D, ell, m)."""
     freqs = np.asarray(freqs, dtype=np.float64)
     lsts = np.atleast_1d(np.asarray(lsts, dtype=np.float64))
     ell, m = _vs.getlm(lmax)
@@ -77,6 +78,8 @@ def vis_proj_operator_no_rot(freqs, lsts, beams, ant_pos, lmax, nside,
 
     resp = project(cross, spec)
     conv = (lambda t: t) if as_torch else (lambda t: t.cpu().numpy())
+    if cross_only:
+        return conv(resp), ell, m
     if not autos_only and not include_autos:
         au = project(autos, None)          # the reference applies no spectral factor to autos
         return conv(resp), conv(au), ell, m
@@ -106,12 +109,24 @@ def healpy2alms(healpy_modes):
     raise ValueError("Input array must have shape (Nmodes,) or (Nmaps, Nmodes).")
 
 
+#: when set to a list, (start, end) HIP events recorded on the launch stream around each
+#: right-hand-side pass over the response operator are appended -- bench.py's roofline
+RHS_EVENTS = None
+
+
 def _adjoint(R, z, scale=None, add=None):
     m, nm = R.shape
     ws = _dev.workspace(_dev._lib.query("hydra_adjoint_workspace_bytes", m, nm))
     out = _dev.empty((nm,), torch.float64)
+    ev = None
+    if RHS_EVENTS is not None:
+        ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+        ev[0].record()
     _dev.call("hydra_adjoint_R", _dev.ptr(R), m, nm, _dev.ptr(z), _dev.ptr(scale), _dev.ptr(add),
               _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+    if ev is not None:
+        ev[1].record()
+        RHS_EVENTS.append(ev)
     return out
 
 
