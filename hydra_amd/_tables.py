@@ -28,6 +28,17 @@ def baseline_indices(ants, antpairs):
     return bl_i, bl_j
 
 
+def is_complete_array(bl_i, bl_j, nant):
+    """True if the baselines are exactly the nant(nant-1)/2 pairs i<j, each once (any order)."""
+    bl_i = np.asarray(bl_i, dtype=np.int64)
+    bl_j = np.asarray(bl_j, dtype=np.int64)
+    if bl_i.size != nant * (nant - 1) // 2 or nant < 2:
+        return False
+    if not np.all(bl_i < bl_j):
+        return False
+    return np.unique(bl_i * nant + bl_j).size == bl_i.size
+
+
 def build_segments(bl_i, bl_j, nant):
     """Segment and row tables for ``hydra_gram_fused``.
 

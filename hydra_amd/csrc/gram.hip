@@ -221,7 +221,7 @@ gram_kernel(const f64x2* __restrict__ R, const f64x2* __restrict__ rows, long lo
 __global__ void __launch_bounds__(256)
 gram_finish_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ns,
                    const double* __restrict__ prior_std, const double* __restrict__ add_diag,
-                   double* __restrict__ G) {
+                   double* __restrict__ G, double scale = 1.0) {
   int tile = blockIdx.x;
   int ti, tj;
   tile_of(tile, &ti, &tj);
@@ -232,6 +232,7 @@ gram_finish_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int
     if (ti == tj && c > r) continue;
     double sum = 0.0;
     for (int s = 0; s < nsplit; ++s) sum += slabs[((size_t)s * ntiles + tile) * TILE_ELEMS + e];
+    sum *= scale;
     if (prior_std) {
       sum = prior_std[gi] * sum * prior_std[gj];
       if (gi == gj) sum = 1.0 + sum;
@@ -462,6 +463,180 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 #endif
 }
 
+
+// ------------------------------------------------------------------ uniform-weight form
+//
+// When every antenna pair i<j is present exactly once and the noise weight of an (f,t) sample is
+// the same for all baselines, the Gram has an exact closed form in the antenna voltages
+// (R'_ij,s = conj(u_i,s) u_j,s, so conj(R'_ij,s) R'_ij,s' = P_i conj(P_j), P_a = u_a,s conj(u_a,s')):
+//
+//   G[s,s'] = sum_ft 1/2 ( |T_ft[s,s']|^2 - sum_a q_a,s q_a,s' ),
+//   T_ft = sum_a u_a,s conj(u_a,s'),  q_a,s = |u_a,s|^2,  u = w_ft^(1/4) |g_a| v_a
+//
+// i.e. per (f,t) a Hermitian rank-Nant update on the matrix cores (K = antennas, not baselines:
+// (Nant-1)/5 times fewer MFMA flops than the baseline form) followed by an element-wise
+// square-accumulate.  T is kept in registers and never stored.  Algorithmic work of THIS kernel:
+// 10 Nant Ns(Ns+1)/2 ... per (f,t) 5 real MFMA products per antenna and output element.
+//
+// Workgroup = 8 waves (4 x 2), output tile 128 x 128, wave tile 32 x 64: per 16x16 block one
+// persistent accumulator (G) and two per-(f,t) accumulators (Re T, Im T).  The scaled voltages
+// of 20 antennas x (128 + 128) sources are one LDS buffer (80 KiB); two buffers are filled
+// alternately by LDS-DMA (global_load_lds_dwordx4, no registers, no VALU) one phase ahead of
+// the MFMA loop that reads the other, so staging hides under the matrix work.
+constexpr int UCH = 20;  // antennas per LDS buffer (5 k-steps of 4)
+
+// U[ft][a][s] = V[ft][a][s] * w_ft^(1/4) * |g_a,ft| for a < nant, 0 for the pad rows a >= nant
+__global__ void __launch_bounds__(256)
+uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
+              const double* __restrict__ wft, int nft, int nant, int nantp, int ns,
+              f64x2* __restrict__ U) {
+  int s = blockIdx.x * blockDim.x + threadIdx.x;
+  int ft = blockIdx.y;
+  if (s >= ns) return;
+  double w4 = wft ? sqrt(sqrt(wft[ft])) : 1.0;
+  for (int a = 0; a < nantp; ++a) {
+    f64x2 u = {0.0, 0.0};
+    if (a < nant) {
+      double f = w4;
+      if (gains) {
+        f64x2 g = gains[(size_t)a * nft + ft];
+        f *= sqrt(g.x * g.x + g.y * g.y);
+      }
+      f64x2 v = V[((size_t)ft * nant + a) * ns + s];
+      u = f64x2{v.x * f, v.y * f};
+    }
+    U[((size_t)ft * nantp + a) * ns + s] = u;
+  }
+}
+
+// wft[ft] = w[0][ft]; *flag |= 1 if any baseline's weight differs from it
+__global__ void __launch_bounds__(256)
+noise_uniform_kernel(const double* __restrict__ w, int nbl, int nft, double* __restrict__ wft,
+                     int32_t* __restrict__ flag) {
+  int ft = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ft >= nft) return;
+  double w0 = w[ft];
+  bool bad = false;
+  for (int b = 1; b < nbl; ++b) bad |= (w[(size_t)b * nft + ft] != w0);
+  wft[ft] = w0;
+  if (bad) atomicOr(flag, 1);
+}
+
+__global__ void __launch_bounds__(512, 1)
+gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int ntiles,
+                    int ft_per_split, double* __restrict__ slabs) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  f64x2* s_u = reinterpret_cast<f64x2*>(smem);  // [2][UCH][256]
+
+  int tile, split;
+  block_work(blockIdx.x, ntiles, &tile, &split);
+  int ti, tj;
+  tile_of(tile, &ti, &tj);
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int kr = lane >> 4, lc = lane & 15;
+  int ft_begin = split * ft_per_split;
+  int ft_end = ft_begin + ft_per_split;
+  if (ft_end > nft) ft_end = nft;
+  const int nc = (nantp + UCH - 1) / UCH;
+  const int nphase = (ft_end > ft_begin) ? (ft_end - ft_begin) * nc : 0;
+
+  // DMA pieces of this wave: piece q = wave + 8 i (i < 10) -> LDS row q >> 2, 64-column segment
+  // q & 3 (segments 0,1: row-tile sources; 2,3: column-tile sources)
+  int seg_col[2];  // source column of this lane for pieces with (q & 3) = (wave & 3) -- fixed per wave
+  {
+    int sg = wave & 3;
+    int col = (sg < 2) ? ti * TS + sg * 64 + lane : tj * TS + (sg - 2) * 64 + lane;
+    seg_col[0] = min(col, ns - 1);
+  }
+  auto issue = [&](int p) {
+    int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
+    int rows = min(UCH, nantp - c * UCH);
+    const f64x2* src = U + ((size_t)ft * nantp + c * UCH) * ns + seg_col[0];
+#pragma unroll
+    for (int i = 0; i < 10; ++i) {
+      int q = wave + 8 * i;
+      int row = q >> 2;  // (q & 3) == (wave & 3)
+      if (row < rows) {
+        f64x2* dst = s_u + ((size_t)(buf * UCH + row) * 256 + (q & 3) * 64);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(src + (size_t)row * ns),
+            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+      }
+    }
+  };
+
+  f64x4 G[2][4], Tre[2][4], Tim[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) G[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+
+  if (nphase > 0) issue(0);
+  const int offA = wr * 32 + lc;
+  const int offB = 128 + wc * 64 + lc;
+  for (int p = 0; p < nphase; ++p) {
+    int c = p % nc, buf = p & 1;
+    __syncthreads();  // phase p has landed (the compiler drains vmcnt before the barrier) and
+                      // every wave has finished reading the other buffer
+    if (p + 1 < nphase) issue(p + 1);
+    if (c == 0) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          Tre[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+          Tim[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+        }
+    }
+    int ksteps = min(UCH, nantp - c * UCH) >> 2;
+    const f64x2* ub = s_u + (size_t)(buf * UCH + kr) * 256;
+#pragma unroll
+    for (int kk = 0; kk < UCH / 4; ++kk) {
+      if (kk < ksteps) {
+        const f64x2* up = ub + kk * 4 * 256;
+        double ax[2], ay[2], nax[2], nq[2];
+#pragma unroll
+        for (int rb = 0; rb < 2; ++rb) {
+          f64x2 a = up[offA + rb * 16];
+          ax[rb] = a.x; ay[rb] = a.y; nax[rb] = -a.x;
+          nq[rb] = -(a.x * a.x + a.y * a.y);
+        }
+#pragma unroll
+        for (int cb = 0; cb < 4; ++cb) {
+          f64x2 b = up[offB + cb * 16];
+          double bq = b.x * b.x + b.y * b.y;
+#pragma unroll
+          for (int rb = 0; rb < 2; ++rb) {
+            Tre[rb][cb] = mfma(ax[rb], b.x, Tre[rb][cb]);
+            Tim[rb][cb] = mfma(ay[rb], b.x, Tim[rb][cb]);
+            Tre[rb][cb] = mfma(ay[rb], b.y, Tre[rb][cb]);
+            Tim[rb][cb] = mfma(nax[rb], b.y, Tim[rb][cb]);
+            G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
+          }
+        }
+      }
+    }
+    if (c == nc - 1) {
+#pragma unroll
+      for (int i = 0; i < 2; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            G[i][j][g] += Tre[i][j][g] * Tre[i][j][g] + Tim[i][j][g] * Tim[i][j][g];
+    }
+  }
+  double* slab = slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS;
+#pragma unroll
+  for (int rb = 0; rb < 2; ++rb)
+#pragma unroll
+    for (int cb = 0; cb < 4; ++cb)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        slab[(size_t)(wr * 32 + rb * 16 + kr + 4 * g) * TS + wc * 64 + cb * 16 + lc] = G[rb][cb][g];
+}
+
 }  // namespace hydra
 
 using namespace hydra;
@@ -600,6 +775,63 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
   HYDRA_CHECK_LAUNCH("hydra_gram_fused");
   gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused(finish)");
+  return HYDRA_OK;
+}
+
+
+size_t hydra_gram_uniform_workspace_bytes(int nf, int nt, int nant, int ns) {
+  if (nf <= 0 || nt <= 0 || nant <= 0 || ns <= 0) return 0;
+  int ntiles, nsplit;
+  long long per;
+  gram_plan((long long)nf * nt, ns, &ntiles, &nsplit, &per, 1, 1);
+  size_t slabs = align_up((size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double), 256);
+  int nantp = (nant + 3) / 4 * 4;
+  return slabs + (size_t)nf * nt * nantp * ns * 16;
+}
+
+int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, double* w_ft,
+                           int32_t* flag, void* stream) {
+  HYDRA_CHECK_ARG(inv_noise && w_ft && flag && nbl > 0 && nf > 0 && nt > 0,
+                  "hydra_noise_uniformity: bad arguments");
+  int nft = nf * nt;
+  noise_uniform_kernel<<<(nft + 255) / 256, 256, 0, as_stream(stream)>>>(inv_noise, nbl, nft, w_ft,
+                                                                         flag);
+  HYDRA_CHECK_LAUNCH("hydra_noise_uniformity");
+  return HYDRA_OK;
+}
+
+int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const double* gains,
+                       const double* w_ft, const double* prior_std, const double* add_diag,
+                       double* G, void* workspace, size_t workspace_bytes, void* stream) {
+  HYDRA_CHECK_ARG(V && G, "hydra_gram_uniform: null pointer argument");
+  HYDRA_CHECK_ARG(nf > 0 && nt > 0 && nant > 1 && ns > 0, "hydra_gram_uniform: bad sizes");
+  HYDRA_CHECK_ARG(!(prior_std && add_diag),
+                  "hydra_gram_uniform: give at most one of prior_std, add_diag");
+  HYDRA_CHECK_ARG((long long)nf * nt <= 65535, "hydra_gram_uniform: nf*nt must be <= 65535");
+  size_t need = hydra_gram_uniform_workspace_bytes(nf, nt, nant, ns);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_gram_uniform: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int nft = nf * nt;
+  int nantp = (nant + 3) / 4 * 4;
+  int ntiles, nsplit;
+  long long per;
+  gram_plan(nft, ns, &ntiles, &nsplit, &per, 1, 1);
+  double* slabs = static_cast<double*>(workspace);
+  size_t slab_bytes = align_up((size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double), 256);
+  f64x2* U = reinterpret_cast<f64x2*>(static_cast<unsigned char*>(workspace) + slab_bytes);
+  hipStream_t st = as_stream(stream);
+  dim3 ugrid((ns + 255) / 256, nft);
+  uscale_kernel<<<ugrid, 256, 0, st>>>(reinterpret_cast<const f64x2*>(V),
+                                       reinterpret_cast<const f64x2*>(gains), w_ft, nft, nant, nantp,
+                                       ns, U);
+  HYDRA_CHECK_LAUNCH("hydra_gram_uniform(scale)");
+  size_t lds = (size_t)2 * UCH * 256 * 16;
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel), lds)) return rc;
+  gram_uniform_kernel<<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles, (int)per, slabs);
+  HYDRA_CHECK_LAUNCH("hydra_gram_uniform");
+  gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G, 0.5);
+  HYDRA_CHECK_LAUNCH("hydra_gram_uniform(finish)");
   return HYDRA_OK;
 }
 

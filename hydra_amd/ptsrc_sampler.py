@@ -57,6 +57,10 @@ class FactoredProj:
         self.seg_host, self.rowtab_host = _tables.build_segments(bl_i, bl_j, nant)
         self.seg = _dev.i32(self.seg_host)
         self.rowtab = _dev.i32(self.rowtab_host)
+        #: every antenna pair i<j exactly once -> the closed-form Gram applies (csrc/gram.hip)
+        self.complete = _tables.is_complete_array(self.bl_i_host, self.bl_j_host, nant)
+        #: set False to force the general (per-baseline weights) Gram kernel
+        self.allow_uniform = True
 
     @property
     def nbytes_materialised(self):
@@ -95,9 +99,33 @@ class FactoredProj:
         return out
 
     def gram(self, gains, inv_noise, prior_std=None, add_diag=None):
-        """Re(R'^H N^-1 R') on the FP64 matrix cores, R' = diag(g_i conj g_j) R."""
+        """Re(R'^H N^-1 R') on the FP64 matrix cores, R' = diag(g_i conj g_j) R.
+
+        General form: rank-Nbl update per (f,t) with per-baseline weights (gram_fused_kernel).
+        If the array is complete and the weights do not depend on the baseline, the exact
+        closed form in the antenna voltages is used instead (gram_uniform_kernel)."""
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
+        if self.complete and self.allow_uniform and nf * nt <= 65535 and nant > 1:
+            w_ft = None
+            uniform = True
+            if inv_noise is not None:
+                w_ft = _dev.empty((nf * nt,), torch.float64)
+                flag = _dev.zeros((1,), torch.int32)
+                _dev.call("hydra_noise_uniformity", _dev.ptr(inv_noise), nbl, nf, nt,
+                          _dev.ptr(w_ft), _dev.ptr(flag), _dev.stream_ptr())
+                uniform = int(flag.item()) == 0
+            if uniform:
+                nbytes = _dev._lib.query("hydra_gram_uniform_workspace_bytes", nf, nt, nant, ns)
+                ws = _dev.workspace(nbytes)
+                G = _dev.empty((ns, ns), torch.float64)
+                _dev.call("hydra_gram_uniform", _dev.ptr(self.V), nf, nt, nant, ns,
+                          _dev.ptr(gains), _dev.ptr(w_ft), _dev.ptr(prior_std),
+                          _dev.ptr(add_diag), _dev.ptr(G), _dev.ptr(ws), ws.numel(),
+                          _dev.stream_ptr())
+                self.last_gram_kernel = "gram_uniform_kernel"
+                return G
+        self.last_gram_kernel = "gram_fused_kernel"
         nbytes = _dev._lib.query("hydra_gram_fused_workspace_bytes", nf, nt, nbl, ns)
         ws = _dev.workspace(nbytes)
         G = _dev.empty((ns, ns), torch.float64)

@@ -134,6 +134,23 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
                      int nseg, int nrows, const double* prior_std, const double* add_diag,
                      double* G, void* workspace, size_t workspace_bytes, void* stream);
 
+/* The same Gram for the common case where (a) every antenna pair i<j appears exactly once and
+ * (b) the noise weight of an (f,t) sample is the same for all baselines: exact closed form in
+ * the antenna voltages,
+ *   G[s,s'] = sum_ft 1/2 ( |sum_a u_a,s conj(u_a,s')|^2 - sum_a |u_a,s|^2 |u_a,s'|^2 ),
+ *   u_a = w_ft^(1/4) |g_a| V[f,t,a,:],
+ * a Hermitian rank-Nant update per (f,t) on the matrix cores instead of a rank-Nbl one
+ * (same result as hydra_gram_fused up to rounding; ptsrc_sampler.py:48-94).
+ * w_ft (Nf*Nt) f64 or NULL (= 1); gains (Nant,Nf,Nt) c128 or NULL.  Epilogues as hydra_gram.
+ * hydra_noise_uniformity fills w_ft[f,t] = inv_noise[0,f,t] and sets *flag (device int32,
+ * caller-zeroed) to 1 if any baseline's weight differs, i.e. if (b) does not hold.          */
+int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, double* w_ft,
+                           int32_t* flag, void* stream);
+size_t hydra_gram_uniform_workspace_bytes(int nf, int nt, int nant, int ns);
+int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const double* gains,
+                       const double* w_ft, const double* prior_std, const double* add_diag,
+                       double* G, void* workspace, size_t workspace_bytes, void* stream);
+
 /* ---- operator application (RHS, matrix-free LHS, model update) ------------------- */
 
 /* out[r] = rowmul[r] * sum_s R[r,s] x[s]   (M) c128; x (Ns) f64; rowmul (M) c128 or NULL

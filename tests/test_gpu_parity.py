@@ -554,3 +554,67 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
     Aref = np.column_stack([gcr_gain.apply_operator(e, w, ps, i1, i2, mv, Fb) for e in np.eye(n)])
     x_ref = np.linalg.solve(Aref, b_ref)
     assert relerr(x, x_ref) < SAMPLE_TOL
+
+
+# ------------------------------------------------------------------ closed-form (antenna-space) Gram
+
+@pytest.mark.parametrize("nant,ns,nf,nt", [(10, 100, 3, 4), (37, 300, 2, 3), (45, 130, 2, 2),
+                                           (64, 257, 1, 3)])
+def test_uniform_weight_gram_matches_oracle_and_general_kernel(hy, orc, nant, ns, nf, nt):
+    """Complete array + noise weights independent of the baseline: precompute_mpi takes the
+    closed-form kernel (gram_uniform_kernel).  It must agree with the oracle's
+    ptsrc_sampler.precompute restatement and with the general per-baseline kernel, with gains
+    varying over (antenna, f, t) and weights varying over (f, t).  nant = 45 / 64 exercise an
+    odd / even number of 20-antenna LDS phases, ns = 130 / 257 the edge tiles."""
+    rng = np.random.RandomState(nant)
+    ant_pos = {a: np.array([rng.uniform(-150, 150), rng.uniform(-150, 150), 0.0])
+               for a in range(nant)}
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    rng.shuffle(antpairs)                       # completeness does not depend on the order
+    antpairs = [tuple(p) for p in antpairs]
+    nbl = len(antpairs)
+    np.random.seed(3)
+    ra, dec, amps = orc.helpers.generate_random_ptsrc_catalogue(ns, (0.0, 1.0), (-0.6, 0.4))
+    freqs = np.linspace(100.0, 120.0, max(nf, 2))[:nf]
+    times = np.linspace(0.2, 0.5, max(nt, 2))[:nt]
+    fluxes = orc.helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    gains = (1.0 + 0.5j) + 0.2 * (rng.randn(nant, nf, nt) + 1j * rng.randn(nant, nf, nt))
+    w_ft = 100.0 + 400.0 * rng.rand(nf, nt)
+    inv_noise = np.broadcast_to(w_ft, (nbl, nf, nt)).copy()
+    data = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    om_n = (rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)) / np.sqrt(2)
+    om_a = rng.randn(ns)
+    prior = 0.05 + 0.1 * rng.rand(ns)
+
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    proj_ref = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
+    A_ref, b_ref = orc.ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
+                                        omega_n=om_n, omega_a=om_a)
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    fac = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh,
+                                              materialize=False)
+    assert fac.complete
+    A_u, b_u = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
+                                               inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
+    assert fac.last_gram_kernel == "gram_uniform_kernel"
+    assert relerr(A_u, A_ref) < OP_TOL and relerr(b_u, b_ref) < OP_TOL
+    assert np.array_equal(A_u, A_u.T)
+    fac.allow_uniform = False
+    A_g, _ = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
+                                             inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
+    assert fac.last_gram_kernel == "gram_fused_kernel"
+    assert relerr(A_u, A_g) < 1e-12
+    # one baseline with a different weight: the closed form does not apply and must not be taken
+    fac.allow_uniform = True
+    inv_noise[3, 0, 0] *= 0.5
+    A_ref2, _ = orc.ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
+                                     omega_n=om_n, omega_a=om_a)
+    A_2, _ = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
+                                             inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
+    assert fac.last_gram_kernel == "gram_fused_kernel"
+    assert relerr(A_2, A_ref2) < OP_TOL
+    # an incomplete array (one pair missing) never takes it
+    fac2 = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs[:-1], freqs,
+                                               times, bh, materialize=False)
+    assert not fac2.complete
