@@ -50,6 +50,12 @@ SH_CONFIGS = {
     "c3": ((7, 13), 40, 32, 128, 4),
     "c3s": ((4, 7), 10, 8, 8, 3),
 }
+GAIN_CONFIGS = {
+    # linearised gain head -- name: (hex_spec, Nf, Nt, nmaxfreq, nmaxtime, batch)
+    # c4 = BASELINE config 4 (HERA-331 per-antenna perturbations, batched CG matvecs)
+    "c4": ((11, 21), 64, 64, 2, 2, 8),
+    "c4s": ((4, 7), 16, 12, 2, 2, 8),
+}
 
 
 def synth_inputs(hex_spec, ns, nf, nt):
@@ -294,12 +300,146 @@ def main_sh(args, comm, rank, world, dev):
     print(json.dumps(out))
 
 
+def main_gain(args, comm, rank, world, dev):
+    """GCR samples/s of the linearised gain head (example.py:673-745): per sample the residual
+    d - g g* V, the right-hand side (gain_sampler.construct_rhs_mpi) and a CG solve of
+    x + S^1/2 F^H A^H N^-1 A F S^1/2 x = b with the matrix-free operator (use_norm_tol=True as in
+    the driver).  Frequency channels are sharded over ranks; the operator result is all-reduced
+    once per CG iteration.  Also times the batched operator (``batch`` vectors per pass over the
+    weights) for the HBM roofline of the pair kernel."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import gain_sampler as gs
+    hex_spec, nf, nt, nmaxf, nmaxt, batch = GAIN_CONFIGS[args.config]
+    ant_pos = hy.utils.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    nbl = len(antpairs)
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    fidx = np.array_split(np.arange(nf), world)[rank]
+    nf_loc = fidx.size
+    Fb_all, _, _ = hy.utils.partial_fourier_basis_2d_from_nmax(
+        freqs, times, nmaxf, nmaxt, freqs[-1] - freqs[0], times[-1] - times[0])
+    nmodes = Fb_all.shape[0]
+    Fb = torch.as_tensor(np.ascontiguousarray(Fb_all[:, fidx, :]), device=dev)
+    ps = torch.full((nmodes,), 0.05, dtype=torch.float64, device=dev)
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(1 + rank)
+    shape = (nbl, nf_loc, nt)
+    model = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    gains = torch.as_tensor((1.0 + 1.0j) + 0.05 * (np.random.RandomState(2).randn(nant)
+                            + 1j * np.random.RandomState(3).randn(nant)), device=dev)
+    gains = gains[:, None, None].expand(nant, nf_loc, nt).contiguous()
+    sigma = 0.05
+    inv_noise = torch.full(shape, 1.0 / sigma ** 2, dtype=torch.float64, device=dev)
+    A_real, A_imag = gs.proj_operator(ants, antpairs)
+    n = 2 * nant * nmodes
+    rng = np.random.RandomState(7)
+    x_true = torch.as_tensor(rng.randn(n), device=dev)
+    # data = g g* (1 + x_i + x_j*) V + noise, with x = F S^1/2 x_true per antenna
+    ggv = hy.utils.apply_gains(model, gains, ants, antpairs, inline=False)
+    op0 = gs.GainOperator(inv_noise, ps, A_real, A_imag, ggv, Fb)
+    g_field = torch.empty((1, nant, nf_loc * nt), dtype=torch.complex128, device=dev)
+    from hydra_amd import _dev as dv
+    dv.call("hydra_gain_basis_fwd", dv.ptr(x_true.reshape(1, -1)), 1, nant, nmodes, nf_loc * nt,
+            dv.ptr(Fb), dv.ptr(ps), dv.ptr(g_field), dv.stream_ptr())
+    data = ggv + gs.apply_proj(g_field.reshape(nant, nf_loc, nt), A_real, A_imag, ggv)
+    data = data + sigma * torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    del op0, g_field
+    m_loc, m_all = nbl * nf_loc * nt, nbl * nf * nt
+
+    def sync():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    def one_sample(k):
+        ggv_k = hy.utils.apply_gains(model, gains, ants, antpairs, inline=False)
+        resid = data - ggv_k
+        om_y = torch.randn((nant, nmodes), dtype=torch.complex128, device="cpu",
+                           generator=torch.Generator().manual_seed(1000 + k)).numpy()
+        om_r = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+        b = gs.construct_rhs_mpi(comm, resid, inv_noise, ps, A_real, A_imag, ggv_k, Fb,
+                                 omega_y=om_y, omega_r=om_r)
+        op = gs.GainOperator(inv_noise, ps, A_real, A_imag, ggv_k, Fb)
+        if comm is None:
+            lin = op.apply
+        else:
+            def lin(v):
+                t = op.local(v)
+                comm.allreduce_(t)
+                return v + t
+        x, iters = hy.linear_solver.cg(None, b, linear_op=lin, use_norm_tol=True,
+                                       abs_tol=args.cg_tol, maxiters=1000, return_iters=True)
+        return op, b, x, iters
+
+    for k in range(args.warmup):
+        one_sample(k)
+    sync()
+    t0 = time.perf_counter()
+    for k in range(args.steps):
+        op, b, x, iters = one_sample(100 + k)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if comm is not None:
+        comm.allreduce_(t_all, op="max")
+    elapsed = float(t_all.item())
+
+    # batched operator: HIP events on the launch stream around `reps` applications
+    X = torch.randn((batch, n), dtype=torch.float64, device=dev, generator=gen)
+    op.local(X)
+    reps = 10
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(reps):
+        op.local(X)
+    e1.record()
+    torch.cuda.synchronize()
+    mv_ms = e0.elapsed_time(e1) / reps
+    if rank != 0:
+        return
+    lhs = x + op.local(x) if comm is None else None
+    resid_rel = float((torch.linalg.norm(lhs - b) / torch.linalg.norm(b)).item()) if lhs is not None \
+        else float("nan")
+    alg_bytes = 8.0 * m_loc              # SURVEY 8(d): the fused real weight, read once
+    achieved = alg_bytes / (mv_ms * 1e-3) / 1e9
+    out = {
+        "metric": "GCR samples/sec (gain head, whole job)",
+        "value": args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE config {args.config}: linearised gain GCR, hex{hex_spec} = {nant} "
+                         f"antennas / {nbl} baselines, {nf} freqs x {nt} times, {nmodes} Fourier "
+                         f"modes per antenna ({n} real unknowns), matrix-free CG, complex128"),
+            "rows_M": m_all, "solver": "cg (use_norm_tol)", "cg_abs_tol": args.cg_tol,
+            "cg_iters_last": int(iters),
+            "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
+        },
+        "sample_rel_residual": resid_rel,
+        "batched_matvec": {"vectors": batch, "ms": mv_ms,
+                           "matvecs_per_s": batch / (mv_ms * 1e-3)},
+        "roofline": {
+            "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
+            "frac": achieved / 8000.0, "traffic": None, "kernel": "gain_pairs_kernel (+ basis "
+            "transforms) for a batch of %d vectors" % batch, "ms_per_launch": mv_ms,
+            "bytes_per_launch": alg_bytes,
+        },
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + sorted(SH_CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + sorted(SH_CONFIGS) + sorted(GAIN_CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cg-tol", type=float, default=1e-8)
     ap.add_argument("--gram", default="auto", choices=["auto", "general"],
@@ -324,6 +464,8 @@ def main():
     dev = _dev.device()
     if args.config in SH_CONFIGS:
         return main_sh(args, comm, rank, world, dev)
+    if args.config in GAIN_CONFIGS:
+        return main_gain(args, comm, rank, world, dev)
 
     hex_spec, ns, nf, nt = CONFIGS[args.config]
     inp = synth_inputs(hex_spec, ns, nf, nt)

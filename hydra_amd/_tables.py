@@ -13,18 +13,30 @@ ROW_BYTES = 256 * 16          # one antenna: 128 + 128 sources, complex128
 INFO_BYTES = 12               # per baseline row: packed LDS rows (4) + sqrt weight (8)
 
 
+_BL_CACHE = {}
+
+
 def baseline_indices(ants, antpairs):
     """Index of each baseline's antennas in ``ants`` (the lookup of
-    ptsrc_sampler.py:53-56 / utils.py:102-105).  Returns int32 arrays (bl_i, bl_j)."""
-    ants = [a for a in np.atleast_1d(np.asarray(ants)).tolist()]
+    ptsrc_sampler.py:53-56 / utils.py:102-105).  Returns int32 arrays (bl_i, bl_j).
+    The result is cached per (antpairs, ants) object pair: the heads call this every Gibbs
+    iteration with the same lists (54 615 pairs for HERA-331)."""
+    key = (id(antpairs), id(ants))
+    hit = _BL_CACHE.get(key)
+    if hit is not None and hit[0] is antpairs and hit[1] is ants and hit[2] == len(antpairs):
+        return hit[3], hit[4]
+    ants_l = [a for a in np.atleast_1d(np.asarray(ants)).tolist()]
     pos = {}
-    for k, a in enumerate(ants):
+    for k, a in enumerate(ants_l):
         pos.setdefault(a, k)
     try:
         bl_i = np.array([pos[p[0]] for p in antpairs], dtype=np.int32)
         bl_j = np.array([pos[p[1]] for p in antpairs], dtype=np.int32)
     except KeyError as exc:
         raise IndexError(f"antenna {exc.args[0]} of `antpairs` is not in `ants`") from exc
+    if len(_BL_CACHE) > 16:
+        _BL_CACHE.clear()
+    _BL_CACHE[key] = (antpairs, ants, len(antpairs), bl_i, bl_j)
     return bl_i, bl_j
 
 
