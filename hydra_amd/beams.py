@@ -106,3 +106,76 @@ def group_beams(beams):
             uniq.append(b)
             idx.append(len(uniq) - 1)
     return uniq, np.asarray(idx, dtype=np.int32)
+
+
+class GriddedBeam:
+    """Power beam tabulated on a regular (za, az) grid per frequency -- the role of a pyuvdata
+    ``UVBeam`` in az_za coordinates (BASELINE config 5 "UVBeam interp").
+
+    Interpolation follows pyuvdata's ``az_za_simple`` recipe as the reference drives it
+    (``reuse_spline=True, freq_interp_kind="cubic"``, vis_simulator.py:340-349): cubic
+    ``interp1d`` in frequency on the grid, then a bicubic ``RectBivariateSpline`` in (za, az).
+    The spline FIT (small: one grid per channel) is done once per channel on the host with
+    scipy and cached; the EVALUATION at Nsrc x Ntimes points per channel -- the part the
+    reference repeats per antenna, time and frequency -- runs on the GPU
+    (``hydra_beam_bspline``).  A full-circle azimuth grid is extended by a wrapped column."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, freqs_hz, za_grid, az_grid, power, freq_interp_kind="cubic"):
+        self.freqs = np.asarray(freqs_hz, dtype=np.float64)
+        self.za_grid = np.asarray(za_grid, dtype=np.float64)
+        az = np.asarray(az_grid, dtype=np.float64)
+        power = np.asarray(power, dtype=np.float64)
+        if power.shape != (self.freqs.size, self.za_grid.size, az.size):
+            raise ValueError("power must have shape (Nfreq, Nza, Naz)")
+        daz = az[1] - az[0]
+        if np.isclose(az[-1] - az[0] + daz, 2.0 * np.pi):
+            az = np.concatenate([az, [az[0] + 2.0 * np.pi]])
+            power = np.concatenate([power, power[:, :, :1]], axis=2)
+        if self.za_grid.size < 4 or az.size < 4:
+            raise ValueError("a bicubic spline needs at least 4 grid points per axis")
+        self.az_grid, self.power, self.kind = az, power, freq_interp_kind
+        self._fits = {}
+
+    def _grid_at(self, freq):
+        from scipy.interpolate import interp1d
+        if self.freqs.size == 1:
+            return self.power[0]
+        return interp1d(self.freqs, self.power, kind=self.kind, axis=0)(freq)
+
+    def _fit(self, freq):
+        """(tx, ty, coefficients) of the interpolating bicubic spline at ``freq`` (cached)."""
+        key = float(freq)
+        if key not in self._fits:
+            from scipy.interpolate import RectBivariateSpline
+            spl = RectBivariateSpline(self.za_grid, self.az_grid, self._grid_at(freq), kx=3, ky=3)
+            tx, ty = spl.get_knots()
+            self._fits[key] = (np.ascontiguousarray(tx), np.ascontiguousarray(ty),
+                               np.ascontiguousarray(spl.get_coeffs()))
+        return self._fits[key]
+
+    def device_response(self, az, za, freqs_hz):
+        """Power values (Nfreq,) + az.shape as a GPU tensor; ``az``, ``za`` GPU tensors."""
+        import torch
+        from . import _dev
+        freqs_hz = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
+        fits = [self._fit(f) for f in freqs_hz]
+        tx, ty = fits[0][0], fits[0][1]
+        coef = _dev.f64(np.stack([f[2] for f in fits]))
+        tx_d, ty_d = _dev.f64(tx), _dev.f64(ty)
+        az_d, za_d = _dev.f64(az), _dev.f64(za)
+        npts = az_d.numel()
+        out = _dev.empty((freqs_hz.size,) + tuple(az_d.shape), torch.float64)
+        _dev.call("hydra_beam_bspline", _dev.ptr(tx_d), tx.size, _dev.ptr(ty_d), ty.size,
+                  _dev.ptr(coef), freqs_hz.size, _dev.ptr(za_d), _dev.ptr(az_d), npts,
+                  _dev.ptr(out), _dev.stream_ptr())
+        return out
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        """Host-array interface of the beam protocol (evaluated on the GPU as well)."""
+        out = self.device_response(np.asarray(az_array, dtype=np.float64),
+                                   np.asarray(za_array, dtype=np.float64), freq_array)
+        return out.cpu().numpy()[np.newaxis, np.newaxis, :, :]

@@ -151,6 +151,68 @@ voltages_kernel(const double* __restrict__ antpos, int nant, const double* __res
   }
 }
 
+
+// ---------------------------------------------------------------- gridded (spline) beams
+
+// Cubic B-spline basis at x for the knot span l (t[l] <= x < t[l+1]): FITPACK fpbspl, k = 3.
+__device__ __forceinline__ void bspl3(const double* __restrict__ t, int l, double x, double h[4]) {
+  double hh[3];
+  h[0] = 1.0;
+#pragma unroll
+  for (int j = 1; j <= 3; ++j) {
+#pragma unroll
+    for (int i = 0; i < j; ++i) hh[i] = h[i];
+    h[0] = 0.0;
+#pragma unroll
+    for (int i = 1; i <= j; ++i) {
+      double tli = t[l + i], tlj = t[l + i - j];
+      double f = hh[i - 1] / (tli - tlj);
+      h[i - 1] += f * (tli - x);
+      h[i] = f * (x - tlj);
+    }
+  }
+}
+// span index as in FITPACK bispeu: largest l in [3, n-5] with t[l] <= x (x clamped to the domain)
+__device__ __forceinline__ int bspl_span(const double* __restrict__ t, int n, double* x) {
+  double tb = t[3], te = t[n - 4];
+  if (*x < tb) *x = tb;
+  if (*x > te) *x = te;
+  int lo = 3, hi = n - 5;
+  while (lo < hi) {
+    int mid = (lo + hi + 1) >> 1;
+    if (t[mid] <= *x) lo = mid; else hi = mid - 1;
+  }
+  return lo;
+}
+
+// out[f, p] = sum_ab Bx_a(x_p) By_b(y_p) coef[f][(lx-3+a) * (ny-4) + (ly-3+b)]
+__global__ void __launch_bounds__(256)
+bspline2d_kernel(const double* __restrict__ tx, int nx, const double* __restrict__ ty, int ny,
+                 const double* __restrict__ coef, int nf, const double* __restrict__ x,
+                 const double* __restrict__ y, size_t npts, double* __restrict__ out) {
+  size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= npts) return;
+  double xv = x[p], yv = y[p];
+  int lx = bspl_span(tx, nx, &xv), ly = bspl_span(ty, ny, &yv);
+  double hx[4], hy[4];
+  bspl3(tx, lx, xv, hx);
+  bspl3(ty, ly, yv, hy);
+  int ncy = ny - 4;
+  size_t ncoef = (size_t)(nx - 4) * ncy;
+  for (int f = 0; f < nf; ++f) {
+    const double* c = coef + f * ncoef + (size_t)(lx - 3) * ncy + (ly - 3);
+    double sum = 0.0;
+#pragma unroll
+    for (int a = 0; a < 4; ++a) {
+      double row = 0.0;
+#pragma unroll
+      for (int b = 0; b < 4; ++b) row += c[(size_t)a * ncy + b] * hy[b];
+      sum += hx[a] * row;
+    }
+    out[f * npts + p] = sum;
+  }
+}
+
 // ---------------------------------------------------------------- baseline products
 
 // R[b,f,t,s] = conj(V[f,t,i_b,s]) V[f,t,j_b,s].  A workgroup stages the voltages of all
@@ -432,6 +494,20 @@ int hydra_row_factors(const double* gains, const double* inv_noise, const int32_
       reinterpret_cast<const f64x2*>(gains), inv_noise, bl_i, bl_j, nft,
       reinterpret_cast<f64x2*>(gg), reinterpret_cast<f64x2*>(rows));
   HYDRA_CHECK_LAUNCH("hydra_row_factors");
+  return HYDRA_OK;
+}
+
+
+int hydra_beam_bspline(const double* tx, int nx, const double* ty, int ny, const double* coef,
+                       int nf, const double* x, const double* y, long long npts, double* out,
+                       void* stream) {
+  HYDRA_CHECK_ARG(tx && ty && coef && x && y && out, "hydra_beam_bspline: null pointer argument");
+  HYDRA_CHECK_ARG(nx >= 8 && ny >= 8 && nf > 0 && npts > 0,
+                  "hydra_beam_bspline: need nx, ny >= 8 knots (cubic), nf, npts > 0");
+  unsigned grid = (unsigned)((npts + 255) / 256);
+  bspline2d_kernel<<<grid, 256, 0, as_stream(stream)>>>(tx, nx, ty, ny, coef, nf, x, y,
+                                                        (size_t)npts, out);
+  HYDRA_CHECK_LAUNCH("hydra_beam_bspline");
   return HYDRA_OK;
 }
 

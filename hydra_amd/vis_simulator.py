@@ -74,13 +74,20 @@ def _host_beam_values(uniq, freqs, eq2tops_d, crd_eq_d, nt, ns):
     up = _dev.empty((nt, ns), torch.uint8)
     _dev.call("hydra_az_za", _dev.ptr(eq2tops_d), nt, _dev.ptr(crd_eq_d), ns, _dev.ptr(az),
               _dev.ptr(za), _dev.ptr(up), _dev.stream_ptr())
-    az_h, za_h = az.cpu().numpy(), za.cpu().numpy()
-    vals = np.empty((len(uniq), freqs.size, nt, ns), dtype=np.float64)
+    vals = _dev.empty((len(uniq), freqs.size, nt, ns), torch.float64)
+    az_h = za_h = None
     for k, bm in enumerate(uniq):
+        if hasattr(bm, "device_response"):      # gridded beams: spline evaluated on the GPU
+            vals[k] = bm.device_response(az, za, freqs)
+            continue
+        if az_h is None:
+            az_h, za_h = az.cpu().numpy(), za.cpu().numpy()
+        host = np.empty((freqs.size, nt, ns), dtype=np.float64)
         for t in range(nt):
             resp = bm.compute_response(az_array=az_h[t], za_array=za_h[t],
                                        freq_array=np.atleast_1d(freqs))
-            vals[k, :, t, :] = np.asarray(resp)[0][0]
+            host[:, t, :] = np.asarray(resp)[0][0]
+        vals[k] = _dev.f64(host)
     return vals
 
 

@@ -57,6 +57,17 @@ int hydra_eq2tops(const double* lsts, int nt, double latitude, double* eq2tops, 
 int hydra_az_za(const double* eq2tops, int nt, const double* crd_eq, int ns, double* az,
                 double* za, uint8_t* above, void* stream);
 
+/* Gridded (UVBeam-style) power beam: bicubic tensor-product B-spline evaluated at npts points,
+ * for nf coefficient sets that share the knots (one set per frequency channel):
+ *   out[f,p] = sum_ab B_a(x_p; tx) B_b(y_p; ty) coef[f][(lx-3+a)(ny-4) + (ly-3+b)]
+ * -- the evaluation half of scipy.interpolate.RectBivariateSpline.ev (FITPACK bispeu), which is
+ * what pyuvdata's az_za_simple beam interpolation calls with reuse_spline=True
+ * (vis_simulator.py:340-349).  x = za, y = az; arguments are clamped to the knot domain.
+ * tx (nx), ty (ny) knots and coef (nf, (nx-4)(ny-4)) come from the host-side fit.          */
+int hydra_beam_bspline(const double* tx, int nx, const double* ty, int ny, const double* coef,
+                       int nf, const double* x, const double* y, long long npts, double* out,
+                       void* stream);
+
 /* ---- response generator ---------------------------------------------------------- */
 
 /* Antenna voltages V (Nf,Nt,Nant,Ns) c128:

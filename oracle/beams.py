@@ -115,3 +115,44 @@ class TabulatedBeam:
             out.append((1 - w) * self._interp_one(self.power[k], az, za)
                        + w * self._interp_one(self.power[k + 1], az, za))
         return np.asarray(out)[np.newaxis, np.newaxis, :, :]
+
+
+class SplineBeam:
+    """Power beam on a regular (za, az) grid per frequency, interpolated the way pyuvdata's
+    ``UVBeam`` does for ``interpolation_function="az_za_simple"`` (the reference calls it with
+    ``reuse_spline=True, freq_interp_kind="cubic"``, vis_simulator.py:340-349): the grid is
+    first interpolated to the requested frequency with ``scipy.interpolate.interp1d(kind=...)``
+    and then evaluated with a bicubic ``scipy.interpolate.RectBivariateSpline(za, az, grid)``.
+    A grid that covers the full circle in azimuth is extended by one wrapped column at
+    az0 + 2 pi.  pyuvdata itself is not installed: the scipy calls are the pinned part, the
+    wrap / clamping conventions are restated from memory (PARITY UNPINNED for those)."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, freqs_hz, za_grid, az_grid, power, freq_interp_kind="cubic"):
+        self.freqs = np.asarray(freqs_hz, dtype=np.float64)
+        self.za_grid = np.asarray(za_grid, dtype=np.float64)
+        az = np.asarray(az_grid, dtype=np.float64)
+        power = np.asarray(power, dtype=np.float64)
+        assert power.shape == (self.freqs.size, self.za_grid.size, az.size)
+        daz = az[1] - az[0]
+        if np.isclose(az[-1] - az[0] + daz, 2.0 * np.pi):
+            az = np.concatenate([az, [az[0] + 2.0 * np.pi]])
+            power = np.concatenate([power, power[:, :, :1]], axis=2)
+        self.az_grid, self.power, self.kind = az, power, freq_interp_kind
+
+    def grid_at(self, freq):
+        from scipy.interpolate import interp1d
+        if self.freqs.size == 1:
+            return self.power[0]
+        return interp1d(self.freqs, self.power, kind=self.kind, axis=0)(freq)
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        from scipy.interpolate import RectBivariateSpline
+        az = np.asarray(az_array, dtype=np.float64)
+        za = np.asarray(za_array, dtype=np.float64)
+        out = [RectBivariateSpline(self.za_grid, self.az_grid, self.grid_at(f), kx=3, ky=3)
+               .ev(za, az) for f in np.atleast_1d(freq_array)]
+        return np.asarray(out)[np.newaxis, np.newaxis, :, :]

@@ -275,6 +275,7 @@ def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, 
     kw = dict(data_chunk=data, inv_noise_var_chunk=inv_noise, gain_chunk=gains,
               amp_prior_std=prior, omega_n=om_n, omega_a=om_a)
     A_f, b_f = hy.ptsrc_sampler.precompute_mpi(*args, proj_chunk=fac, **kw)
+    assert fac.last_gram_kernel == "gram_fused_kernel"      # per-baseline weights: general kernel
     A_m, b_m = hy.ptsrc_sampler.precompute_mpi(*args, proj_chunk=R, **kw)
     for A, b in ((A_f, b_f), (A_m, b_m)):
         assert relerr(A, A_ref) < OP_TOL
@@ -618,3 +619,53 @@ def test_uniform_weight_gram_matches_oracle_and_general_kernel(hy, orc, nant, ns
     fac2 = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs[:-1], freqs,
                                                times, bh, materialize=False)
     assert not fac2.complete
+
+
+# ------------------------------------------------------------------ gridded (spline) beams
+
+def _gridded_beam_pair(hy, orc, nfreq=5):
+    za = np.linspace(0.0, np.pi / 2, 46)
+    az = np.arange(0.0, 360.0, 4.0) * np.pi / 180.0
+    freqs = np.linspace(95e6, 125e6, nfreq)
+    rng = np.random.RandomState(2)
+    nu = (freqs - 100e6) / 20e6
+    grid = (np.exp(-(za[None, :, None] / (0.25 + 0.05 * nu[:, None, None])) ** 2)
+            * (1.0 + 0.2 * np.cos(2 * az[None, None, :]) * np.sin(za[None, :, None]) ** 2)
+            + 0.02 + 1e-4 * rng.rand(nfreq, za.size, az.size))
+    return (hy.beams.GriddedBeam(freqs, za, az, grid), orc.beams.SplineBeam(freqs, za, az, grid))
+
+
+def test_gridded_beam_device_spline_matches_scipy(hy, orc):
+    """hydra_beam_bspline (de Boor on the GPU) against scipy's RectBivariateSpline.ev -- the
+    routine pyuvdata's az_za_simple interpolation calls -- incl. points on knots, on the domain
+    edges and outside the domain (clamped), and cubic interpolation in frequency."""
+    bh, bo = _gridded_beam_pair(hy, orc)
+    rng = np.random.RandomState(4)
+    zq = np.concatenate([rng.uniform(0.0, np.pi / 2, 3000), bo.za_grid[::5], [0.0, np.pi / 2],
+                         [-0.01, np.pi / 2 + 0.2]])
+    aq = np.concatenate([rng.uniform(0.0, 2 * np.pi, 3000), bo.az_grid[:zq.size - 3000]])
+    aq = aq[:zq.size]
+    fq = np.array([95e6, 101.7e6, 118.2e6, 125e6])
+    got = bh.compute_response(az_array=aq, za_array=zq, freq_array=fq)
+    want = bo.compute_response(az_array=aq, za_array=zq, freq_array=fq)
+    assert got.shape == want.shape == (1, 1, fq.size, zq.size)
+    assert relerr(got, want) < 1e-13
+
+
+def test_simulator_with_gridded_beams_matches_oracle(hy, orc):
+    """Per-source response and point-source GCR system with one shared gridded beam (evaluated
+    once on the GPU) and with a mix of gridded and analytic beams (value-table path)."""
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup((3, 4), 60, 3, 4, seed=9, wide=True)
+    nant = len(ant_pos)
+    bh, bo = _gridded_beam_pair(hy, orc)
+    for mixed in (False, True):
+        beams_h = [bh] * nant
+        beams_o = [bo] * nant
+        if mixed:
+            beams_h = [bh if a % 2 else hy.beams.GaussianBeam(diameter=14.0) for a in range(nant)]
+            beams_o = [bo if a % 2 else orc.beams.GaussianBeam(diameter=14.0) for a in range(nant)]
+        ref = orc.response.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
+                                                   beams_o, latitude=LAT)
+        got = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6,
+                                                       times, beams_h, latitude=LAT)
+        assert relerr(got, ref) < OP_TOL

@@ -249,3 +249,31 @@ def test_sh_response_operator_shapes_and_consistency():
     sc = ((freqs / 100.0) ** -2.5)[None, :, None, None]
     assert np.allclose(proj2.reshape(3, freqs.size, lsts.size, -1),
                        proj.reshape(3, freqs.size, lsts.size, -1) * sc)
+
+
+def test_spline_beam_reproduces_a_smooth_beam_and_wraps_in_azimuth():
+    """oracle.beams.SplineBeam (scipy interp1d + RectBivariateSpline, the pyuvdata az_za_simple
+    recipe): a finely gridded smooth beam is reproduced, azimuth is periodic across 2 pi, and
+    the cubic frequency interpolation is exact for a cubic frequency dependence."""
+    from oracle import beams as obeams
+    za = np.linspace(0.0, np.pi / 2, 91)
+    az = np.arange(0.0, 360.0, 2.0) * np.pi / 180.0
+    freqs = np.linspace(100e6, 120e6, 6)
+
+    def truth(f, z, a):
+        nu = (f - 100e6) / 20e6
+        return np.exp(-(z / 0.3) ** 2) * (1.0 + 0.2 * np.cos(2 * a) * np.sin(z) ** 2) \
+            * (1.0 + 0.3 * nu - 0.2 * nu ** 2 + 0.1 * nu ** 3)
+    grid = truth(freqs[:, None, None], za[None, :, None], az[None, None, :])
+    bm = obeams.SplineBeam(freqs, za, az, grid)
+    rng = np.random.RandomState(0)
+    zq = rng.uniform(0.0, np.pi / 2, 500)
+    aq = rng.uniform(0.0, 2 * np.pi, 500)
+    fq = np.array([103.3e6, 117.9e6])
+    got = bm.compute_response(az_array=aq, za_array=zq, freq_array=fq)[0, 0]
+    want = truth(fq[:, None], zq[None, :], aq[None, :])
+    assert np.max(np.abs(got - want)) < 1e-5      # interpolation error of a 1 x 2 degree grid
+    lo = bm.compute_response(az_array=np.array([1e-9]), za_array=np.array([0.4]), freq_array=fq)
+    hi = bm.compute_response(az_array=np.array([2 * np.pi - 1e-9]), za_array=np.array([0.4]),
+                             freq_array=fq)
+    assert np.max(np.abs(lo - hi)) < 1e-8
