@@ -41,6 +41,10 @@ CONFIGS = {
     "c2": ((4, 7), 2000, 64, 200),
     "mid": ((4, 7), 1000, 16, 50),
     "c1": ((3, 4), 100, 16, 20),
+    # c5s = BASELINE config 5 scaled to one box-minute: the 350-antenna layout (331-element hex +
+    # 19 outriggers on a 300 m ring), gridded beam with bicubic interpolation,
+    # baseline-sharded Gram + all-reduce; 8192 sources instead of 100 000, 8 channels x 1 time
+    "c5s": ((11, 21), 8192, 8, 1),
 }
 SH_CONFIGS = {
     # spherical-harmonic head -- name: (hex_spec, lmax, nside, Nf, Nt)
@@ -58,13 +62,18 @@ GAIN_CONFIGS = {
 }
 
 
-def synth_inputs(hex_spec, ns, nf, nt):
+def synth_inputs(hex_spec, ns, nf, nt, outriggers=0):
     """Synthetic inputs of SURVEY section 8(d): hex array (14.6 m), random catalogue seed 0,
     100-120 MHz, LST 0.2-0.5 rad, Gaussian beam D = 14 m, gains (1+1j) + 0.05 N(0,1),
     sigma_noise = 0.05, prior std 0.1."""
     from hydra_amd import example, utils
     np.random.seed(0)
     ant_pos = utils.build_hex_array(hex_spec=hex_spec, d=14.6)
+    if outriggers:
+        n0 = len(ant_pos)
+        for k in range(outriggers):
+            ang = 2.0 * np.pi * k / outriggers
+            ant_pos[n0 + k] = np.array([300.0 * np.cos(ang), 300.0 * np.sin(ang), 0.0])
     nant = len(ant_pos)
     antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
     ra, dec, amps = example.generate_random_ptsrc_catalogue(ns, (0.0, 1.0), (-0.6, 0.4),
@@ -446,6 +455,8 @@ def main():
                     help="auto = closed-form antenna-space Gram when the array is complete and the "
                          "noise weights do not depend on the baseline (true for this workload), "
                          "general = always the per-baseline-weight kernel")
+    ap.add_argument("--shard", default=None, choices=["freq", "baseline"],
+                    help="how the visibility rows are split over GPUs (default: freq; c5s: baseline)")
     ap.add_argument("--solver", default="dense", choices=["dense", "cg"],
                     help="dense = blocked Cholesky (the reference's default for this head, "
                          "example.py:944); cg = linear_solver.cg")
@@ -468,20 +479,39 @@ def main():
         return main_gain(args, comm, rank, world, dev)
 
     hex_spec, ns, nf, nt = CONFIGS[args.config]
-    inp = synth_inputs(hex_spec, ns, nf, nt)
-    ant_pos, antpairs = inp["ant_pos"], inp["antpairs"]
-    nant, nbl = len(ant_pos), len(antpairs)
+    big = args.config == "c5s"
+    shard = args.shard or ("baseline" if big else "freq")
+    inp = synth_inputs(hex_spec, ns, nf, nt, outriggers=19 if big else 0)
+    ant_pos, antpairs_all = inp["ant_pos"], inp["antpairs"]
+    nant = len(ant_pos)
     ants = np.arange(nant)
-    fidx = np.array_split(np.arange(nf), world)[rank]          # frequency sharding
+    if shard == "freq":
+        fidx = np.array_split(np.arange(nf), world)[rank]      # frequency sharding
+        antpairs = antpairs_all
+    else:
+        fidx = np.arange(nf)                                    # baseline sharding (round-robin)
+        antpairs = antpairs_all[rank::world]
+    nbl, nbl_all = len(antpairs), len(antpairs_all)
     nf_loc = fidx.size
     freqs_loc = inp["freqs"][fidx]
     times = inp["times"]
-    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    if big:
+        # gridded beam table (181 x 360 at 1 degree, 3 channels) with the Gaussian's shape
+        za_g = np.linspace(0.0, np.pi, 181)
+        az_g = np.arange(360) * np.pi / 180.0
+        f_g = np.array([90e6, 105e6, 120e6, 135e6])
+        sig = hy.beams.GaussianBeam(diameter=14.0).get_sigmas(f_g)
+        tab = np.exp(-(za_g[None, :, None] / sig[:, None, None]) ** 2) * np.ones((1, 1, az_g.size)) \
+            + 1e-3
+        gb = hy.beams.GriddedBeam(f_g, za_g, az_g, tab)
+        beams = [gb for _ in ant_pos]
+    else:
+        beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
 
     # ---- set-up (untimed): factored operator, gains, data, noise weights -- all in HBM
     fac = ptsrc_sampler.calc_proj_operator(inp["ra"], inp["dec"], inp["fluxes"][:, fidx], ant_pos,
                                            antpairs, freqs_loc, times, beams, materialize=False)
-    fac.allow_uniform = args.gram == "auto"
+    fac.allow_uniform = args.gram == "auto" and shard == "freq"
     gains = torch.as_tensor(inp["g0"], device=dev)[:, None, None].expand(nant, nf_loc, nt).contiguous()
     gg = _dev.empty((nbl, nf_loc, nt), torch.complex128)
     _dev.call("hydra_row_factors", _dev.ptr(gains), _dev.ptr(None), _dev.ptr(fac.bl_i),
@@ -496,7 +526,7 @@ def main():
     prior = torch.as_tensor(inp["prior"], device=dev)
     del gg
     m_loc = nbl * nf_loc * nt
-    m_all = nbl * nf * nt
+    m_all = nbl_all * nf * nt
 
     def one_sample():
         om_n = torch.randn((nbl, nf_loc, nt), dtype=torch.complex128, device=dev, generator=gen)
@@ -567,11 +597,12 @@ def main():
         "data": "synthetic",
         "config": {
             "workload": (f"BASELINE config {args.config}: ptsrc GCR, hex{hex_spec} = {nant} antennas "
-                         f"/ {nbl} baselines, {ns} sources, {nf} freqs x {nt} times, complex128, "
-                         f"factored operator (R never materialised)"),
+                         f"/ {nbl_all} baselines, {ns} sources, {nf} freqs x {nt} times, complex128, "
+                         f"factored operator (R never materialised)"
+                         + (", gridded beam (bicubic spline)" if big else "")),
             "rows_M": m_all, "solver": args.solver, "cg_abs_tol": args.cg_tol,
             "cg_iters_last": int(iters), "gram": args.gram,
-            "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
+            "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU",
         },
         # the metric's "Gram FP64 TFLOP/s": baseline-form flops 2 M Ns (Ns+1) over the Gram time,
         # whole job (exceeds the matrix peak when the antenna-form kernel does the same Gram with
@@ -588,6 +619,9 @@ def main():
     }
     if not args.no_cpu:
         nf_s, nt_s = (2, 10) if args.config == "c2" else (min(nf, 2), min(nt, 10))
+        if big:      # a 2000-baseline, one-channel slice (the full slice would need 16 GB)
+            inp = dict(inp, antpairs=antpairs_all[:2000])
+            nf_s, nt_s = 1, 1
         out["cpu_baseline"] = cpu_baseline(inp, nf_s, nt_s, m_all)
     else:
         out["cpu_baseline"] = None

@@ -121,21 +121,26 @@ scale_rows_kernel(const f64x2* y, const double* __restrict__ w, long long m, f64
 
 // ---------------------------------------------------------------- factored form
 
-constexpr int VCH = 64;        // sources staged per pass
-constexpr int VPAD = VCH + 1;  // padded LDS row (16-B elements) -> rows land on different banks
+// Sources staged per pass: 64 normally, 16 when the array is so large that all antennas x 64
+// sources would not fit in the 160 KiB of LDS (HERA-350).  Rows are padded by one 16-B element
+// so that different antennas land on different banks.
 
 // out[b,ft] = rowmul[b,ft] * sum_s conj(V[ft,i_b,s]) V[ft,j_b,s] x[s]
 // One workgroup per (f,t): voltages staged 64 sources at a time, thread <-> baseline.
+template <int VCH>
 __global__ void __launch_bounds__(256)
 apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
                const double* __restrict__ x, const f64x2* __restrict__ rowmul,
                f64x2* __restrict__ out, int bl_per_thread) {
   extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int VPAD = VCH + 1;
+  constexpr int NSUB = 64 / VCH;  // antennas staged per wave pass
   f64x2* s_v = reinterpret_cast<f64x2*>(smem);                       // [nant][VPAD]
   double* s_x = reinterpret_cast<double*>(s_v + (size_t)nant * VPAD);  // [VCH]
   int ft = blockIdx.x;
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  int slane = lane % VCH, sub = lane / VCH;
   const f64x2* vft = V + (size_t)ft * nant * ns;
   // up to 8 baselines per thread are accumulated in registers per pass over the sources
   constexpr int MAXB = 8;
@@ -152,9 +157,9 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     }
     for (int s0 = 0; s0 < ns; s0 += VCH) {
       __syncthreads();
-      int s = s0 + lane;
-      for (int a = wave; a < nant; a += 4)
-        s_v[a * VPAD + lane] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
+      int s = s0 + slane;
+      for (int a = wave * NSUB + sub; a < nant; a += 4 * NSUB)
+        s_v[a * VPAD + slane] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
       if (tid < VCH) s_x[tid] = (s0 + tid < ns) ? x[s0 + tid] : 0.0;
       __syncthreads();
 #pragma unroll
@@ -199,16 +204,20 @@ ctranspose_kernel(const f64x2* __restrict__ in, int nbl, int nft, f64x2* __restr
 }
 
 // partial[split][s] = sum_{ft in split} sum_b Re( V_i,s conj(V_j,s) z[b,ft] )
-// Workgroup <-> (64-source chunk, ft range); 4 waves split the baselines, lanes own sources.
+// Workgroup <-> (CW-source chunk, ft range); the 256 threads are CW sources x (256/CW) baseline
+// groups; fixed-order reduction over the groups through LDS.  CW = 64 normally, 16 for arrays
+// too large to stage all antennas x 64 sources.
+template <int CW>
 __global__ void __launch_bounds__(256)
 adjoint_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                  const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
                  const f64x2* __restrict__ zt, int ft_per_split, double* __restrict__ partial) {
+  constexpr int NG = 256 / CW;
   extern __shared__ __align__(16) unsigned char smem[];
-  f64x2* s_v = reinterpret_cast<f64x2*>(smem);  // [nant][64]
-  double* s_red = reinterpret_cast<double*>(s_v + (size_t)nant * 64);  // [4][64]
-  int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  int s = blockIdx.x * 64 + lane;
+  f64x2* s_v = reinterpret_cast<f64x2*>(smem);  // [nant][CW]
+  double* s_red = reinterpret_cast<double*>(s_v + (size_t)nant * CW);  // [NG][CW]
+  int tid = threadIdx.x, sl = tid % CW, grp = tid / CW;
+  int s = blockIdx.x * CW + sl;
   int ft0 = blockIdx.y * ft_per_split;
   int ft1 = ft0 + ft_per_split;
   if (ft1 > nft) ft1 = nft;
@@ -217,20 +226,22 @@ adjoint_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     const f64x2* vft = V + (size_t)ft * nant * ns;
     const f64x2* zft = zt + (size_t)ft * nbl;
     __syncthreads();
-    for (int a = wave; a < nant; a += 4)
-      s_v[a * 64 + lane] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
+    for (int a = grp; a < nant; a += NG)
+      s_v[a * CW + sl] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
     __syncthreads();
-    for (int b = wave; b < nbl; b += 4) {
-      f64x2 r = cmul_conj(s_v[bl_i[b] * 64 + lane], s_v[bl_j[b] * 64 + lane]);  // R[b,s]
+    for (int b = grp; b < nbl; b += NG) {
+      f64x2 r = cmul_conj(s_v[bl_i[b] * CW + sl], s_v[bl_j[b] * CW + sl]);  // R[b,s]
       f64x2 zb = zft[b];
       acc += r.x * zb.x + r.y * zb.y;  // Re(conj(R) z)
     }
   }
   __syncthreads();
-  s_red[wave * 64 + lane] = acc;
+  s_red[grp * CW + sl] = acc;
   __syncthreads();
-  if (wave == 0 && s < ns) {
-    double t = (s_red[lane] + s_red[64 + lane]) + (s_red[128 + lane] + s_red[192 + lane]);
+  if (grp == 0 && s < ns) {
+    double t = 0.0;
+#pragma unroll
+    for (int g = 0; g < NG; ++g) t += s_red[g * CW + sl];
     partial[(size_t)blockIdx.y * ns + s] = t;
   }
 }
@@ -244,7 +255,7 @@ static void adjoint_plan(long long m, int ns, int* nchunk, long long* rows_per_c
 }
 
 static void adjoint_V_plan(int nft, int ns, int* nsplit, int* per) {
-  int chunks = (ns + 63) / 64;
+  int chunks = (ns + 63) / 64;   // (sized for the 64-wide kernel; the 16-wide one just has more chunks)
   int want = std::max(1, std::min(nft, 2048 / chunks));
   *per = (nft + want - 1) / want;
   *nsplit = (nft + *per - 1) / *per;
@@ -326,12 +337,21 @@ int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32
                   double* out, void* stream) {
   HYDRA_CHECK_ARG(V && bl_i && bl_j && x && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
                   "hydra_apply_V: bad arguments");
-  size_t lds = ((size_t)nant * VPAD) * 16 + VCH * 8;
-  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_apply_V: nant=%d exceeds the LDS staging limit", nant);
-  if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel), lds)) return rc_lds;
-  apply_V_kernel<<<nf * nt, 256, lds, as_stream(stream)>>>(
-      reinterpret_cast<const f64x2*>(V), nf * nt, nant, ns, bl_i, bl_j, nbl, x,
-      reinterpret_cast<const f64x2*>(rowmul), reinterpret_cast<f64x2*>(out), 0);
+  const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
+  const f64x2* rm = reinterpret_cast<const f64x2*>(rowmul);
+  f64x2* op = reinterpret_cast<f64x2*>(out);
+  size_t lds64 = ((size_t)nant * 65) * 16 + 64 * 8, lds16 = ((size_t)nant * 17) * 16 + 16 * 8;
+  if (lds64 <= 160 * 1024) {
+    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<64>), lds64)) return rc_lds;
+    apply_V_kernel<64><<<nf * nt, 256, lds64, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,
+                                                                   nbl, x, rm, op, 0);
+  } else {
+    HYDRA_CHECK_ARG(lds16 <= 160 * 1024, "hydra_apply_V: nant=%d exceeds the LDS staging limit (600)",
+                    nant);
+    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<16>), lds16)) return rc_lds;
+    apply_V_kernel<16><<<nf * nt, 256, lds16, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,
+                                                                   nbl, x, rm, op, 0);
+  }
   HYDRA_CHECK_LAUNCH("hydra_apply_V");
   return HYDRA_OK;
 }
@@ -353,8 +373,10 @@ int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int
   if (!workspace || workspace_bytes < need)
     return fail(HYDRA_ERR_WORKSPACE, "hydra_adjoint_V: workspace too small (%zu < %zu bytes)",
                 workspace_bytes, need);
-  size_t lds = (size_t)nant * 64 * 16 + 4 * 64 * 8;
-  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_adjoint_V: nant=%d exceeds the LDS staging limit", nant);
+  size_t lds64 = (size_t)nant * 64 * 16 + 256 * 8, lds16 = (size_t)nant * 16 * 16 + 256 * 8;
+  bool wide = lds64 <= 160 * 1024;
+  HYDRA_CHECK_ARG(wide || lds16 <= 160 * 1024,
+                  "hydra_adjoint_V: nant=%d exceeds the LDS staging limit (630)", nant);
   int nft = nf * nt, nsplit, per;
   adjoint_V_plan(nft, ns, &nsplit, &per);
   HYDRA_CHECK_ARG(nsplit <= 65535, "hydra_adjoint_V: too many splits");
@@ -364,10 +386,16 @@ int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int
   hipStream_t st = as_stream(stream);
   ctranspose_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const f64x2*>(z), nbl, nft, zt);
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V(transpose)");
-  if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_kernel), lds)) return rc_lds;
-  dim3 grid((ns + 63) / 64, nsplit);
-  adjoint_V_kernel<<<grid, 256, lds, st>>>(reinterpret_cast<const f64x2*>(V), nft, nant, ns, bl_i,
-                                           bl_j, nbl, zt, per, partial);
+  const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
+  if (wide) {
+    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_kernel<64>), lds64)) return rc_lds;
+    dim3 grid((ns + 63) / 64, nsplit);
+    adjoint_V_kernel<64><<<grid, 256, lds64, st>>>(Vp, nft, nant, ns, bl_i, bl_j, nbl, zt, per, partial);
+  } else {
+    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_kernel<16>), lds16)) return rc_lds;
+    dim3 grid((ns + 15) / 16, nsplit);
+    adjoint_V_kernel<16><<<grid, 256, lds16, st>>>(Vp, nft, nant, ns, bl_i, bl_j, nbl, zt, per, partial);
+  }
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V");
   adjoint_reduce_kernel<<<(ns + 255) / 256, 256, 0, st>>>(partial, nsplit, ns, scale, add, out);
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V(reduce)");

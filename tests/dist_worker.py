@@ -158,6 +158,35 @@ def case_ptsrc(comm):
     comm.barrier()
 
 
+def case_blshard(comm):
+    """Baseline-sharded precompute_mpi (rank r owns antpairs[r::size], all channels): the
+    all-reduced Gram / RHS equal the single-process system (BASELINE config 5's partitioning)."""
+    import hydra_amd as hy
+    rank, size = comm.Get_rank(), comm.Get_size()
+    p = _ptsrc_inputs()
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in p["ant_pos"]]
+    full = hy.ptsrc_sampler.calc_proj_operator(p["ra"], p["dec"], p["fluxes"], p["ant_pos"],
+                                               p["antpairs"], p["freqs"], p["times"], beams,
+                                               materialize=False)
+    A1, b1 = hy.ptsrc_sampler.precompute_mpi(
+        None, p["ants"], p["antpairs"], p["freqs"], p["times"], full, p["data"], p["inv_noise"],
+        p["gains"], p["prior"], omega_n=p["om_n"], omega_a=p["om_a"])
+    sel = np.arange(len(p["antpairs"]))[rank::size]
+    mypairs = [p["antpairs"][k] for k in sel]
+    mine = hy.ptsrc_sampler.calc_proj_operator(p["ra"], p["dec"], p["fluxes"], p["ant_pos"],
+                                               mypairs, p["freqs"], p["times"], beams,
+                                               materialize=False)
+    assert not mine.complete
+    A2, b2 = hy.ptsrc_sampler.precompute_mpi(
+        comm, p["ants"], mypairs, p["freqs"], p["times"], mine, p["data"][sel],
+        p["inv_noise"][sel], p["gains"], p["prior"], omega_n=p["om_n"][sel], omega_a=p["om_a"])
+    if rank == 0:
+        ea = np.max(np.abs(A2 - A1)) / np.max(np.abs(A1))
+        eb = np.max(np.abs(b2 - b1)) / np.max(np.abs(b1))
+        assert ea < 1e-12 and eb < 1e-12, (ea, eb)
+    comm.barrier()
+
+
 def case_cgmpi(comm):
     """cg_mpi on a 2x2 block grid (linear_solver.py:238-375) == dense solve."""
     from hydra_amd import linear_solver
@@ -188,7 +217,7 @@ if __name__ == "__main__":
     assert comm is not None, "run under torch.distributed.run with WORLD_SIZE > 1"
     try:
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
-         "cgmpi": case_cgmpi}[case](comm)
+         "blshard": case_blshard, "cgmpi": case_cgmpi}[case](comm)
     except BaseException:
         import traceback
         if logdir:

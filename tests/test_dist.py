@@ -55,5 +55,10 @@ def test_freq_sharded_ptsrc_system_world2():
 
 
 @pytest.mark.gpu
+def test_baseline_sharded_ptsrc_system_world3():
+    _run("blshard", 3)
+
+
+@pytest.mark.gpu
 def test_cg_mpi_world4():
     _run("cgmpi", 4)

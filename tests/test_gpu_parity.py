@@ -669,3 +669,36 @@ def test_simulator_with_gridded_beams_matches_oracle(hy, orc):
         got = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6,
                                                        times, beams_h, latitude=LAT)
         assert relerr(got, ref) < OP_TOL
+
+
+def test_large_array_factored_operator_matches_oracle(hy, orc):
+    """170 antennas: all antennas x 64 sources no longer fit in LDS, so R x and R^H z use the
+    16-source staging; the Gram walks 9 x 9 antenna-block segments.  Factored system vs oracle."""
+    nant, ns, nf, nt = 170, 48, 1, 2
+    rng = np.random.RandomState(170)
+    ant_pos = {a: np.array([rng.uniform(-300, 300), rng.uniform(-300, 300), 0.0])
+               for a in range(nant)}
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    nbl = len(antpairs)
+    np.random.seed(5)
+    ra, dec, amps = orc.helpers.generate_random_ptsrc_catalogue(ns, (0.0, 1.0), (-0.6, 0.4))
+    freqs = np.array([110.0])
+    times = np.array([0.25, 0.4])
+    fluxes = orc.helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    gains, inv_noise, prior, om_n, om_a = _gcr_inputs(nbl, nant, nf, nt, ns, seed=3)
+    data = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    proj_ref = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
+    A_ref, b_ref = orc.ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
+                                        omega_n=om_n, omega_a=om_a)
+    fac = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh,
+                                              materialize=False)
+    assert fac.seg_host.shape[0] == 45
+    A, b = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
+                                           inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
+    assert relerr(A, A_ref) < OP_TOL and relerr(b, b_ref) < OP_TOL
+    truth = 1.0 + 0.1 * rng.randn(ns)
+    mod_ref = (proj_ref.reshape(-1, ns) @ truth).reshape(nbl, nf, nt)
+    assert relerr(hy.ptsrc_sampler.apply_proj(fac, truth).cpu().numpy(), mod_ref) < OP_TOL
