@@ -35,6 +35,14 @@ __device__ unsigned long long g_stamps[8];
   __builtin_amdgcn_sched_barrier(0);
 #endif
 
+// Optional HIP events recorded on the launch stream immediately before / after the main Gram
+// kernel (hydra_profile_events): lets a caller time that kernel alone, without the small
+// helper kernels of the same entry point.
+static thread_local hipEvent_t g_prof_ev[2] = {nullptr, nullptr};
+static inline void profile_record(int which, hipStream_t st) {
+  if (g_prof_ev[which]) (void)hipEventRecord(g_prof_ev[which], st);
+}
+
 constexpr int TS = 128;            // workgroup tile edge
 constexpr int TILE_ELEMS = TS * TS;
 
@@ -485,15 +493,21 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 // the MFMA loop that reads the other, so staging hides under the matrix work.
 constexpr int UCH = 20;  // antennas per LDS buffer (5 k-steps of 4)
 
-// U[ft][a][s] = V[ft][a][s] * w_ft^(1/4) * |g_a,ft| for a < nant, 0 for the pad rows a >= nant
+// U[ft][a][s] = V[ft][a][s] * w_ft^(1/4) * |g_a,ft| for a < nant, 0 for the pad rows a >= nant.
+// same_beam: every antenna has the same |v_a,s| (one beam model), so
+//   sum_a q_a,s q_a,s' = (sum_a f_a^4) p_s p_s',  p_s = |v_0,s|^2,
+// and row `nant` carries (sqrt(sum_a f_a^4) p_s, 0): the kernel subtracts that rank-1 term with
+// one MFMA per block and (f,t) instead of one per k-step.
 __global__ void __launch_bounds__(256)
 uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
-              const double* __restrict__ wft, int nft, int nant, int nantp, int ns,
+              const double* __restrict__ wft, int nft, int nant, int nantp, int ns, int same_beam,
               f64x2* __restrict__ U) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   int ft = blockIdx.y;
   if (s >= ns) return;
   double w4 = wft ? sqrt(sqrt(wft[ft])) : 1.0;
+  double c4 = 0.0;
+  f64x2 v0 = {0.0, 0.0};
   for (int a = 0; a < nantp; ++a) {
     f64x2 u = {0.0, 0.0};
     if (a < nant) {
@@ -503,7 +517,12 @@ uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
         f *= sqrt(g.x * g.x + g.y * g.y);
       }
       f64x2 v = V[((size_t)ft * nant + a) * ns + s];
+      if (a == 0) v0 = v;
       u = f64x2{v.x * f, v.y * f};
+      double f2 = f * f;
+      c4 += f2 * f2;
+    } else if (same_beam && a == nant) {
+      u = f64x2{sqrt(c4) * (v0.x * v0.x + v0.y * v0.y), 0.0};
     }
     U[((size_t)ft * nantp + a) * ns + s] = u;
   }
@@ -522,9 +541,10 @@ noise_uniform_kernel(const double* __restrict__ w, int nbl, int nft, double* __r
   if (bad) atomicOr(flag, 1);
 }
 
+template <bool SAMEBEAM>
 __global__ void __launch_bounds__(512, 1)
 gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int ntiles,
-                    int ft_per_split, double* __restrict__ slabs) {
+                    int ft_per_split, int qrow, double* __restrict__ slabs) {
   extern __shared__ __align__(16) unsigned char smem[];
   f64x2* s_u = reinterpret_cast<f64x2*>(smem);  // [2][UCH][256]
 
@@ -596,23 +616,36 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
       if (kk < ksteps) {
         const f64x2* up = ub + kk * 4 * 256;
         double ax[2], ay[2], nax[2], nq[2];
+        // SAMEBEAM: the k-step that holds row `qrow` (wave-uniform test); its lane group
+        // kr == qrow % 4 carries (sqrt(c) p_s, 0), which must stay out of T and go to G
+        bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));
+        bool qlane = qstep && (kr == (qrow & 3));
 #pragma unroll
         for (int rb = 0; rb < 2; ++rb) {
           f64x2 a = up[offA + rb * 16];
+          if (SAMEBEAM) {
+            nq[rb] = qlane ? -a.x : 0.0;
+            if (qlane) a = f64x2{0.0, 0.0};
+          } else {
+            nq[rb] = -(a.x * a.x + a.y * a.y);
+          }
           ax[rb] = a.x; ay[rb] = a.y; nax[rb] = -a.x;
-          nq[rb] = -(a.x * a.x + a.y * a.y);
         }
 #pragma unroll
         for (int cb = 0; cb < 4; ++cb) {
           f64x2 b = up[offB + cb * 16];
-          double bq = b.x * b.x + b.y * b.y;
+          double bq = SAMEBEAM ? b.x : b.x * b.x + b.y * b.y;
 #pragma unroll
           for (int rb = 0; rb < 2; ++rb) {
             Tre[rb][cb] = mfma(ax[rb], b.x, Tre[rb][cb]);
             Tim[rb][cb] = mfma(ay[rb], b.x, Tim[rb][cb]);
             Tre[rb][cb] = mfma(ay[rb], b.y, Tre[rb][cb]);
             Tim[rb][cb] = mfma(nax[rb], b.y, Tim[rb][cb]);
-            G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
+            if (!SAMEBEAM) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
+          }
+          if (SAMEBEAM && qstep) {
+#pragma unroll
+            for (int rb = 0; rb < 2; ++rb) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
           }
         }
       }
@@ -675,13 +708,21 @@ int hydra_gram(const double* R, const double* rows, long long m, int ns, const d
   long long per;
   gram_plan(m, ns, &ntiles, &nsplit, &per, 4, 64);
   double* slabs = static_cast<double*>(workspace);
+  profile_record(0, as_stream(stream));
   gram_kernel<<<ntiles * nsplit, 256, 0, as_stream(stream)>>>(
       reinterpret_cast<const f64x2*>(R), reinterpret_cast<const f64x2*>(rows), m, ns, ntiles, per,
       slabs);
+  profile_record(1, as_stream(stream));
   HYDRA_CHECK_LAUNCH("hydra_gram");
   gram_finish_kernel<<<ntiles, 256, 0, as_stream(stream)>>>(slabs, nsplit, ntiles, ns, prior_std,
                                                             add_diag, G);
   HYDRA_CHECK_LAUNCH("hydra_gram(finish)");
+  return HYDRA_OK;
+}
+
+int hydra_profile_events(void* start_event, void* stop_event) {
+  g_prof_ev[0] = static_cast<hipEvent_t>(start_event);
+  g_prof_ev[1] = static_cast<hipEvent_t>(stop_event);
   return HYDRA_OK;
 }
 
@@ -764,6 +805,7 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
   if (e != hipSuccess)
     return fail(HYDRA_ERR_HIP, "hydra_gram_fused: cannot reserve %zu bytes of LDS: %s", lds,
                 hipGetErrorString(e));
+  profile_record(0, st);
   if (two_groups)
     gram_fused_kernel<2><<<ntiles * nsplit, 512, lds, st>>>(
         reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
@@ -772,6 +814,7 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
     gram_fused_kernel<1><<<ntiles * nsplit, 256, lds, st>>>(
         reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
         sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
+  profile_record(1, st);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused");
   gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused(finish)");
@@ -785,7 +828,7 @@ size_t hydra_gram_uniform_workspace_bytes(int nf, int nt, int nant, int ns) {
   long long per;
   gram_plan((long long)nf * nt, ns, &ntiles, &nsplit, &per, 1, 1);
   size_t slabs = align_up((size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double), 256);
-  int nantp = (nant + 3) / 4 * 4;
+  int nantp = (nant + 1 + 3) / 4 * 4;   // room for the same-beam row
   return slabs + (size_t)nf * nt * nantp * ns * 16;
 }
 
@@ -801,8 +844,9 @@ int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, dou
 }
 
 int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const double* gains,
-                       const double* w_ft, const double* prior_std, const double* add_diag,
-                       double* G, void* workspace, size_t workspace_bytes, void* stream) {
+                       const double* w_ft, int same_beam, const double* prior_std,
+                       const double* add_diag, double* G, void* workspace, size_t workspace_bytes,
+                       void* stream) {
   HYDRA_CHECK_ARG(V && G, "hydra_gram_uniform: null pointer argument");
   HYDRA_CHECK_ARG(nf > 0 && nt > 0 && nant > 1 && ns > 0, "hydra_gram_uniform: bad sizes");
   HYDRA_CHECK_ARG(!(prior_std && add_diag),
@@ -813,7 +857,8 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
     return fail(HYDRA_ERR_WORKSPACE, "hydra_gram_uniform: workspace too small (%zu < %zu bytes)",
                 workspace_bytes, need);
   int nft = nf * nt;
-  int nantp = (nant + 3) / 4 * 4;
+  same_beam = same_beam ? 1 : 0;
+  int nantp = (nant + same_beam + 3) / 4 * 4;
   int ntiles, nsplit;
   long long per;
   gram_plan(nft, ns, &ntiles, &nsplit, &per, 1, 1);
@@ -824,11 +869,20 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   dim3 ugrid((ns + 255) / 256, nft);
   uscale_kernel<<<ugrid, 256, 0, st>>>(reinterpret_cast<const f64x2*>(V),
                                        reinterpret_cast<const f64x2*>(gains), w_ft, nft, nant, nantp,
-                                       ns, U);
+                                       ns, same_beam, U);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform(scale)");
   size_t lds = (size_t)2 * UCH * 256 * 16;
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel), lds)) return rc;
-  gram_uniform_kernel<<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles, (int)per, slabs);
+  profile_record(0, st);
+  if (same_beam) {
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel<true>), lds)) return rc;
+    gram_uniform_kernel<true><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles, (int)per,
+                                                                 nant, slabs);
+  } else {
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel<false>), lds)) return rc;
+    gram_uniform_kernel<false><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles, (int)per,
+                                                                  -1, slabs);
+  }
+  profile_record(1, st);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform");
   gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G, 0.5);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform(finish)");

@@ -29,13 +29,22 @@ GRAM_EVENTS = None
 
 
 def _timed_gram(fn):
+    """Run ``fn`` (one Gram entry point); with GRAM_EVENTS set, have the library record a pair
+    of HIP events on the launch stream right around the main Gram kernel
+    (hydra_profile_events), so the helper kernels of the entry point are not in the bracket."""
     if GRAM_EVENTS is None:
         return fn()
+    import ctypes
     start = torch.cuda.Event(enable_timing=True)
     end = torch.cuda.Event(enable_timing=True)
-    start.record()
-    out = fn()
+    start.record()          # creates the underlying hipEvent_t handles
     end.record()
+    _dev.call("hydra_profile_events", ctypes.c_void_p(start.cuda_event),
+              ctypes.c_void_p(end.cuda_event))
+    try:
+        out = fn()
+    finally:
+        _dev.call("hydra_profile_events", ctypes.c_void_p(0), ctypes.c_void_p(0))
     GRAM_EVENTS.append((start, end))
     return out
 
@@ -61,6 +70,8 @@ class FactoredProj:
         self.complete = _tables.is_complete_array(self.bl_i_host, self.bl_j_host, nant)
         #: set False to force the general (per-baseline weights) Gram kernel
         self.allow_uniform = True
+        #: |V[f,t,a,s]| independent of the antenna (set by the simulator for a single beam model)
+        self.same_beam = bool(getattr(V, "hydra_same_beam", False))
 
     @property
     def nbytes_materialised(self):
@@ -120,7 +131,7 @@ class FactoredProj:
                 ws = _dev.workspace(nbytes)
                 G = _dev.empty((ns, ns), torch.float64)
                 _dev.call("hydra_gram_uniform", _dev.ptr(self.V), nf, nt, nant, ns,
-                          _dev.ptr(gains), _dev.ptr(w_ft), _dev.ptr(prior_std),
+                          _dev.ptr(gains), _dev.ptr(w_ft), int(self.same_beam), _dev.ptr(prior_std),
                           _dev.ptr(add_diag), _dev.ptr(G), _dev.ptr(ws), ws.numel(),
                           _dev.stream_ptr())
                 self.last_gram_kernel = "gram_uniform_kernel"

@@ -138,6 +138,9 @@ def antenna_voltages(antpos, freqs, eq2tops, crd_eq, fluxes, beam_list, beam_idx
               int(bool(force_no_beam_sqrt)), _dev.ptr(V), _dev.ptr(bad), _dev.stream_ptr())
     if int(bad.item()) != 0:
         raise ValueError("Beam interpolation resulted in an invalid value")
+    # one beam model for every antenna: |V[f,t,a,s]| does not depend on a (used by the
+    # closed-form Gram, csrc/gram.hip)
+    V.hydra_same_beam = bool(np.all(idx == idx[0]))
     return V
 
 

@@ -153,14 +153,23 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
  * a Hermitian rank-Nant update per (f,t) on the matrix cores instead of a rank-Nbl one
  * (same result as hydra_gram_fused up to rounding; ptsrc_sampler.py:48-94).
  * w_ft (Nf*Nt) f64 or NULL (= 1); gains (Nant,Nf,Nt) c128 or NULL.  Epilogues as hydra_gram.
+ * same_beam != 0 asserts that |V[f,t,a,s]| does not depend on the antenna a (one beam model for
+ * the whole array, as in hydra/example.py:143-172): the term sum_a |u_a,s|^2 |u_a,s'|^2 is then
+ * rank one per (f,t) and costs one MFMA per output block and (f,t) instead of one per k-step.
  * hydra_noise_uniformity fills w_ft[f,t] = inv_noise[0,f,t] and sets *flag (device int32,
  * caller-zeroed) to 1 if any baseline's weight differs, i.e. if (b) does not hold.          */
 int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, double* w_ft,
                            int32_t* flag, void* stream);
 size_t hydra_gram_uniform_workspace_bytes(int nf, int nt, int nant, int ns);
 int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const double* gains,
-                       const double* w_ft, const double* prior_std, const double* add_diag,
-                       double* G, void* workspace, size_t workspace_bytes, void* stream);
+                       const double* w_ft, int same_beam, const double* prior_std,
+                       const double* add_diag, double* G, void* workspace, size_t workspace_bytes,
+                       void* stream);
+
+/* Profiling hook: HIP events (hipEvent_t, NULL to clear) recorded by this thread's next calls of
+ * hydra_gram_fused / hydra_gram_uniform on their stream immediately before and after the main
+ * Gram kernel.  No counterpart in the reference.                                            */
+int hydra_profile_events(void* start_event, void* stop_event);
 
 /* ---- operator application (RHS, matrix-free LHS, model update) ------------------- */
 

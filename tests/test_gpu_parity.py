@@ -559,14 +559,18 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
 
 # ------------------------------------------------------------------ closed-form (antenna-space) Gram
 
-@pytest.mark.parametrize("nant,ns,nf,nt", [(10, 100, 3, 4), (37, 300, 2, 3), (45, 130, 2, 2),
-                                           (64, 257, 1, 3)])
-def test_uniform_weight_gram_matches_oracle_and_general_kernel(hy, orc, nant, ns, nf, nt):
+@pytest.mark.parametrize("nant,ns,nf,nt,mixed", [(10, 100, 3, 4, False), (37, 300, 2, 3, False),
+                                                 (37, 300, 2, 3, True), (39, 140, 1, 2, False),
+                                                 (40, 140, 1, 2, False), (45, 130, 2, 2, False),
+                                                 (45, 130, 2, 2, True), (64, 257, 1, 3, False)])
+def test_uniform_weight_gram_matches_oracle_and_general_kernel(hy, orc, nant, ns, nf, nt, mixed):
     """Complete array + noise weights independent of the baseline: precompute_mpi takes the
     closed-form kernel (gram_uniform_kernel).  It must agree with the oracle's
     ptsrc_sampler.precompute restatement and with the general per-baseline kernel, with gains
     varying over (antenna, f, t) and weights varying over (f, t).  nant = 45 / 64 exercise an
-    odd / even number of 20-antenna LDS phases, ns = 130 / 257 the edge tiles."""
+    odd / even number of 20-antenna LDS phases, nant = 39 / 40 the position of the same-beam
+    row (last slot of a k-step / a k-step and LDS phase of its own), ns = 130 / 257 the edge
+    tiles; ``mixed`` = two beam models, i.e. the general per-antenna q term."""
     rng = np.random.RandomState(nant)
     ant_pos = {a: np.array([rng.uniform(-150, 150), rng.uniform(-150, 150), 0.0])
                for a in range(nant)}
@@ -588,14 +592,16 @@ def test_uniform_weight_gram_matches_oracle_and_general_kernel(hy, orc, nant, ns
     om_a = rng.randn(ns)
     prior = 0.05 + 0.1 * rng.rand(ns)
 
-    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    # one beam model for the whole array (rank-one q term) or two different ones (general q term)
+    diam = [14.0 if (not mixed or a % 3) else 11.0 for a in range(nant)]
+    bo = [orc.beams.GaussianBeam(diameter=d) for d in diam]
     proj_ref = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
     A_ref, b_ref = orc.ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
                                         omega_n=om_n, omega_a=om_a)
-    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bh = [hy.beams.GaussianBeam(diameter=d) for d in diam]
     fac = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh,
                                               materialize=False)
-    assert fac.complete
+    assert fac.complete and fac.same_beam == (not mixed)
     A_u, b_u = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
                                                inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
     assert fac.last_gram_kernel == "gram_uniform_kernel"
