@@ -32,7 +32,9 @@ def init_from_env(backend=None):
     if world <= 1:
         return None
     if backend is None:
-        backend = "nccl" if torch.cuda.is_available() else "gloo"
+        # HYDRA_DIST_BACKEND=gloo lets several ranks share one GPU (rehearsals on a 1-GPU box)
+        backend = os.environ.get("HYDRA_DIST_BACKEND") or \
+            ("nccl" if torch.cuda.is_available() else "gloo")
     if torch.cuda.is_available():
         torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
     if not dist.is_initialized():

@@ -221,7 +221,7 @@ adjoint_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   int ft0 = blockIdx.y * ft_per_split;
   int ft1 = ft0 + ft_per_split;
   if (ft1 > nft) ft1 = nft;
-  double acc = 0.0;
+  double acc = 0.0, acc2 = 0.0;
   for (int ft = ft0; ft < ft1; ++ft) {
     const f64x2* vft = V + (size_t)ft * nant * ns;
     const f64x2* zft = zt + (size_t)ft * nbl;
@@ -229,12 +229,27 @@ adjoint_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     for (int a = grp; a < nant; a += NG)
       s_v[a * CW + sl] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
     __syncthreads();
-    for (int b = grp; b < nbl; b += NG) {
-      f64x2 r = cmul_conj(s_v[bl_i[b] * CW + sl], s_v[bl_j[b] * CW + sl]);  // R[b,s]
+    // 4 baselines per trip: the (wave-uniform) index and z loads of all four are issued before
+    // the LDS reads, so their latency overlaps instead of serialising per baseline
+    int b = grp;
+    for (; b + 3 * NG < nbl; b += 4 * NG) {
+      int i0 = bl_i[b], i1 = bl_i[b + NG], i2 = bl_i[b + 2 * NG], i3 = bl_i[b + 3 * NG];
+      int j0 = bl_j[b], j1 = bl_j[b + NG], j2 = bl_j[b + 2 * NG], j3 = bl_j[b + 3 * NG];
+      f64x2 z0 = zft[b], z1 = zft[b + NG], z2 = zft[b + 2 * NG], z3 = zft[b + 3 * NG];
+      f64x2 r0 = cmul_conj(s_v[i0 * CW + sl], s_v[j0 * CW + sl]);  // R[b,s]
+      f64x2 r1 = cmul_conj(s_v[i1 * CW + sl], s_v[j1 * CW + sl]);
+      f64x2 r2 = cmul_conj(s_v[i2 * CW + sl], s_v[j2 * CW + sl]);
+      f64x2 r3 = cmul_conj(s_v[i3 * CW + sl], s_v[j3 * CW + sl]);
+      acc += (r0.x * z0.x + r0.y * z0.y) + (r1.x * z1.x + r1.y * z1.y);  // Re(conj(R) z)
+      acc2 += (r2.x * z2.x + r2.y * z2.y) + (r3.x * z3.x + r3.y * z3.y);
+    }
+    for (; b < nbl; b += NG) {
+      f64x2 r = cmul_conj(s_v[bl_i[b] * CW + sl], s_v[bl_j[b] * CW + sl]);
       f64x2 zb = zft[b];
-      acc += r.x * zb.x + r.y * zb.y;  // Re(conj(R) z)
+      acc += r.x * zb.x + r.y * zb.y;
     }
   }
+  acc += acc2;
   __syncthreads();
   s_red[grp * CW + sl] = acc;
   __syncthreads();
