@@ -572,13 +572,14 @@ def main():
     resid = float((torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)).item())
     # Algorithmic flops per launch of the kernel that ran (this rank's rows):
     #   gram_fused_kernel   (baseline form):  2 M Ns (Ns+1)                  [SURVEY 8(d)]
-    #   gram_uniform_kernel (antenna form):   Nft Ns(Ns+1)/2 (10 Nant + 4)   [5 real FMAs per
-    #       antenna and output element + the square-accumulate]; with one beam model for the
-    #       whole array the q term is rank one per (f,t): Nft Ns(Ns+1)/2 (8 Nant + 6)
+    #   gram_uniform_kernel (antenna form, 3-product complex multiply):
+    #       Nft Ns(Ns+1)/2 (8 Nant + 8)   [3 real FMAs for T and 1 for the q term per antenna
+    #       and output element, + 8 flops of square-accumulate]; with one beam model for the
+    #       whole array the q term is rank one per (f,t): Nft Ns(Ns+1)/2 (6 Nant + 10)
     kernel = getattr(fac, "last_gram_kernel", "gram_fused_kernel")
     baseline_form_flops = 2.0 * m_loc * ns * (ns + 1)
     if kernel == "gram_uniform_kernel":
-        per_elem = (8.0 * nant + 6.0) if fac.same_beam else (10.0 * nant + 4.0)
+        per_elem = (6.0 * nant + 10.0) if fac.same_beam else (8.0 * nant + 8.0)
         gram_flops = nf_loc * nt * 0.5 * ns * (ns + 1) * per_elem
     else:
         gram_flops = baseline_form_flops
