@@ -19,6 +19,7 @@
 // tile to a slab and a second kernel sums the slabs in a fixed order (bitwise reproducible,
 // no atomics), mirrors the triangle and applies the prior epilogue.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -481,16 +482,11 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 //   G[s,s'] = sum_ft 1/2 ( |T_ft[s,s']|^2 - sum_a q_a,s q_a,s' ),
 //   T_ft = sum_a u_a,s conj(u_a,s'),  q_a,s = |u_a,s|^2,  u = w_ft^(1/4) |g_a| v_a
 //
-// i.e. per (f,t) a Hermitian rank-Nant update on the matrix cores (K = antennas, not baselines:
-// (Nant-1)/5 times fewer MFMA flops than the baseline form) followed by an element-wise
-// square-accumulate.  T is kept in registers and never stored.  Algorithmic work of THIS kernel:
-// 10 Nant Ns(Ns+1)/2 ... per (f,t) 5 real MFMA products per antenna and output element.
-//
-// Workgroup = 8 waves (4 x 2), output tile 128 x 128, wave tile 32 x 64: per 16x16 block one
-// persistent accumulator (G) and two per-(f,t) accumulators (Re T, Im T).  The scaled voltages
-// of 20 antennas x (128 + 128) sources are one LDS buffer (80 KiB); two buffers are filled
-// alternately by LDS-DMA (global_load_lds_dwordx4, no registers, no VALU) one phase ahead of
-// the MFMA loop that reads the other, so staging hides under the matrix work.
+// i.e. per (f,t) a Hermitian rank-Nant update on the matrix cores (K = antennas, not baselines)
+// followed by an element-wise square-accumulate.  T is kept in registers and never stored.
+// The scaled voltages of 20 antennas are one LDS buffer; two buffers are filled alternately by
+// LDS-DMA (global_load_lds_dwordx4, no registers, no VALU) one phase ahead of the MFMA loop
+// that reads the other, so staging hides under the matrix work.
 constexpr int UCH = 20;  // antennas per LDS buffer (5 k-steps of 4)
 
 // U[ft][a][s] = V[ft][a][s] * w_ft^(1/4) * |g_a,ft| for a < nant, 0 for the pad rows a >= nant.
@@ -541,136 +537,6 @@ noise_uniform_kernel(const double* __restrict__ w, int nbl, int nft, double* __r
   if (bad) atomicOr(flag, 1);
 }
 
-template <bool SAMEBEAM>
-__global__ void __launch_bounds__(512, 1)
-gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int ntiles,
-                    int ft_per_split, int qrow, double* __restrict__ slabs) {
-  extern __shared__ __align__(16) unsigned char smem[];
-  f64x2* s_u = reinterpret_cast<f64x2*>(smem);  // [2][UCH][256]
-
-  int tile, split;
-  block_work(blockIdx.x, ntiles, &tile, &split);
-  int ti, tj;
-  tile_of(tile, &ti, &tj);
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 1, wc = wave & 1;
-  const int kr = lane >> 4, lc = lane & 15;
-  int ft_begin = split * ft_per_split;
-  int ft_end = ft_begin + ft_per_split;
-  if (ft_end > nft) ft_end = nft;
-  const int nc = (nantp + UCH - 1) / UCH;
-  const int nphase = (ft_end > ft_begin) ? (ft_end - ft_begin) * nc : 0;
-
-  // DMA pieces of this wave: piece q = wave + 8 i (i < 10) -> LDS row q >> 2, 64-column segment
-  // q & 3 (segments 0,1: row-tile sources; 2,3: column-tile sources)
-  int seg_col[2];  // source column of this lane for pieces with (q & 3) = (wave & 3) -- fixed per wave
-  {
-    int sg = wave & 3;
-    int col = (sg < 2) ? ti * TS + sg * 64 + lane : tj * TS + (sg - 2) * 64 + lane;
-    seg_col[0] = min(col, ns - 1);
-  }
-  auto issue = [&](int p) {
-    int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
-    int rows = min(UCH, nantp - c * UCH);
-    const f64x2* src = U + ((size_t)ft * nantp + c * UCH) * ns + seg_col[0];
-#pragma unroll
-    for (int i = 0; i < 10; ++i) {
-      int q = wave + 8 * i;
-      int row = q >> 2;  // (q & 3) == (wave & 3)
-      if (row < rows) {
-        f64x2* dst = s_u + ((size_t)(buf * UCH + row) * 256 + (q & 3) * 64);
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + (size_t)row * ns),
-            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
-      }
-    }
-  };
-
-  f64x4 G[2][4], Tre[2][4], Tim[2][4];
-#pragma unroll
-  for (int i = 0; i < 2; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) G[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-
-  if (nphase > 0) issue(0);
-  const int offA = wr * 32 + lc;
-  const int offB = 128 + wc * 64 + lc;
-  for (int p = 0; p < nphase; ++p) {
-    int c = p % nc, buf = p & 1;
-    __syncthreads();  // phase p has landed (the compiler drains vmcnt before the barrier) and
-                      // every wave has finished reading the other buffer
-    if (p + 1 < nphase) issue(p + 1);
-    if (c == 0) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          Tre[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-          Tim[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
-        }
-    }
-    int ksteps = min(UCH, nantp - c * UCH) >> 2;
-    const f64x2* ub = s_u + (size_t)(buf * UCH + kr) * 256;
-#pragma unroll
-    for (int kk = 0; kk < UCH / 4; ++kk) {
-      if (kk < ksteps) {
-        const f64x2* up = ub + kk * 4 * 256;
-        double ax[2], ay[2], nax[2], nq[2];
-        // SAMEBEAM: the k-step that holds row `qrow` (wave-uniform test); its lane group
-        // kr == qrow % 4 carries (sqrt(c) p_s, 0), which must stay out of T and go to G
-        bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));
-        bool qlane = qstep && (kr == (qrow & 3));
-#pragma unroll
-        for (int rb = 0; rb < 2; ++rb) {
-          f64x2 a = up[offA + rb * 16];
-          if (SAMEBEAM) {
-            nq[rb] = qlane ? -a.x : 0.0;
-            if (qlane) a = f64x2{0.0, 0.0};
-          } else {
-            nq[rb] = -(a.x * a.x + a.y * a.y);
-          }
-          ax[rb] = a.x; ay[rb] = a.y; nax[rb] = -a.x;
-        }
-#pragma unroll
-        for (int cb = 0; cb < 4; ++cb) {
-          f64x2 b = up[offB + cb * 16];
-          double bq = SAMEBEAM ? b.x : b.x * b.x + b.y * b.y;
-#pragma unroll
-          for (int rb = 0; rb < 2; ++rb) {
-            Tre[rb][cb] = mfma(ax[rb], b.x, Tre[rb][cb]);
-            Tim[rb][cb] = mfma(ay[rb], b.x, Tim[rb][cb]);
-            Tre[rb][cb] = mfma(ay[rb], b.y, Tre[rb][cb]);
-            Tim[rb][cb] = mfma(nax[rb], b.y, Tim[rb][cb]);
-            if (!SAMEBEAM) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
-          }
-          if (SAMEBEAM && qstep) {
-#pragma unroll
-            for (int rb = 0; rb < 2; ++rb) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
-          }
-        }
-      }
-    }
-    if (c == nc - 1) {
-#pragma unroll
-      for (int i = 0; i < 2; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j)
-#pragma unroll
-          for (int g = 0; g < 4; ++g)
-            G[i][j][g] += Tre[i][j][g] * Tre[i][j][g] + Tim[i][j][g] * Tim[i][j][g];
-    }
-  }
-  double* slab = slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS;
-#pragma unroll
-  for (int rb = 0; rb < 2; ++rb)
-#pragma unroll
-    for (int cb = 0; cb < 4; ++cb)
-#pragma unroll
-      for (int g = 0; g < 4; ++g)
-        slab[(size_t)(wr * 32 + rb * 16 + kr + 4 * g) * TS + wc * 64 + cb * 16 + lc] = G[rb][cb][g];
-}
-
-
 // ---- 3-product form of the closed-form Gram ---------------------------------------------
 // T = sum_a u_s conj(u_s') needs Re T = X^T X' + Y^T Y' and Im T = Y^T X' - X^T Y' (u = x + i y).
 // With P1 = X^T X', P2 = Y^T Y', P3 = (X+Y)^T (X'-Y') = P1 - P2 + Im T:
@@ -705,7 +571,7 @@ __device__ __forceinline__ void k3_tile_of(int p, int nct, int* ti, int* tj) {
 
 template <bool SAMEBEAM>
 __global__ void __launch_bounds__(512, 1)
-gram_uniform_k3_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int ntiles,
+gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int ntiles,
                        int ft_per_split, int qrow, double* __restrict__ slabs) {
   extern __shared__ __align__(16) unsigned char smem[];
   f64x2* s_u = reinterpret_cast<f64x2*>(smem);  // [2][UCH][K3_W]
@@ -760,6 +626,8 @@ gram_uniform_k3_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, 
     __syncthreads();  // phase p has landed (vmcnt drained before the barrier); the other buffer
                       // is no longer being read
     if (p + 1 < nphase) issue(p + 1);
+    int ksteps = min(UCH, nantp - c * UCH) >> 2;
+    const f64x2* ub = s_u + (size_t)(buf * UCH + kr) * K3_W;
     if (c == 0) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -770,45 +638,43 @@ gram_uniform_k3_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, 
           P3[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         }
     }
-    int ksteps = min(UCH, nantp - c * UCH) >> 2;
-    const f64x2* ub = s_u + (size_t)(buf * UCH + kr) * K3_W;
+    auto kstep = [&](int kk) {   // one k-step (4 antennas)
+      const f64x2* up = ub + kk * 4 * K3_W;
+      bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));
+      bool qlane = qstep && (kr == (qrow & 3));
+      double ax[3], ay[3], as[3], nq[3];
 #pragma unroll
-    for (int kk = 0; kk < UCH / 4; ++kk) {
-      if (kk < ksteps) {
-        const f64x2* up = ub + kk * 4 * K3_W;
-        bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));
-        bool qlane = qstep && (kr == (qrow & 3));
-        double ax[3], ay[3], as[3], nq[3];
+      for (int rb = 0; rb < 3; ++rb) {
+        f64x2 a = up[offA + rb * 16];
+        if (SAMEBEAM) {
+          nq[rb] = qlane ? -a.x : 0.0;
+          if (qlane) a = f64x2{0.0, 0.0};
+        } else {
+          nq[rb] = -(a.x * a.x + a.y * a.y);
+        }
+        ax[rb] = a.x; ay[rb] = a.y; as[rb] = a.x + a.y;
+      }
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) {
+        f64x2 b = up[offB + cb * 16];
+        double bd = b.x - b.y;
+        double bq = SAMEBEAM ? b.x : b.x * b.x + b.y * b.y;
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-          f64x2 a = up[offA + rb * 16];
-          if (SAMEBEAM) {
-            nq[rb] = qlane ? -a.x : 0.0;
-            if (qlane) a = f64x2{0.0, 0.0};
-          } else {
-            nq[rb] = -(a.x * a.x + a.y * a.y);
-          }
-          ax[rb] = a.x; ay[rb] = a.y; as[rb] = a.x + a.y;
+          P1[rb][cb] = mfma(ax[rb], b.x, P1[rb][cb]);
+          P2[rb][cb] = mfma(ay[rb], b.y, P2[rb][cb]);
+          P3[rb][cb] = mfma(as[rb], bd, P3[rb][cb]);
+          if (!SAMEBEAM) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
         }
+        if (SAMEBEAM && qstep) {
 #pragma unroll
-        for (int cb = 0; cb < 2; ++cb) {
-          f64x2 b = up[offB + cb * 16];
-          double bd = b.x - b.y;
-          double bq = SAMEBEAM ? b.x : b.x * b.x + b.y * b.y;
-#pragma unroll
-          for (int rb = 0; rb < 3; ++rb) {
-            P1[rb][cb] = mfma(ax[rb], b.x, P1[rb][cb]);
-            P2[rb][cb] = mfma(ay[rb], b.y, P2[rb][cb]);
-            P3[rb][cb] = mfma(as[rb], bd, P3[rb][cb]);
-            if (!SAMEBEAM) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
-          }
-          if (SAMEBEAM && qstep) {
-#pragma unroll
-            for (int rb = 0; rb < 3; ++rb) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
-          }
+          for (int rb = 0; rb < 3; ++rb) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
         }
       }
-    }
+    };
+#pragma unroll
+    for (int kk = 0; kk < UCH / 4; ++kk)
+      if (kk < ksteps) kstep(kk);
     if (c == nc - 1) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -817,8 +683,8 @@ gram_uniform_k3_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, 
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             double tre = P1[i][j][g] + P2[i][j][g];
-            double tim = (P3[i][j][g] - P1[i][j][g]) + P2[i][j][g];
-            G[i][j][g] += tre * tre + tim * tim;
+            double tim = P3[i][j][g] - (P1[i][j][g] - P2[i][j][g]);
+            G[i][j][g] = fma(tim, tim, fma(tre, tre, G[i][j][g]));
           }
     }
   }
@@ -1072,12 +938,12 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   size_t lds = (size_t)2 * UCH * K3_W * 16;
   profile_record(0, st);
   if (same_beam) {
-    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_k3_kernel<true>), lds)) return rc;
-    gram_uniform_k3_kernel<true><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles,
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel<true>), lds)) return rc;
+    gram_uniform_kernel<true><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles,
                                                                     (int)per, nant, slabs);
   } else {
-    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_k3_kernel<false>), lds)) return rc;
-    gram_uniform_k3_kernel<false><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles,
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel<false>), lds)) return rc;
+    gram_uniform_kernel<false><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles,
                                                                      (int)per, -1, slabs);
   }
   profile_record(1, st);
