@@ -220,6 +220,143 @@ sh_project_kernel(const f64x2* __restrict__ V, int nft, int nant, int npix,
     }
 }
 
+
+// ---- pixel -> mode projection, tiled form --------------------------------------------------
+// Same contraction as sh_project_kernel, restructured for the matrix pipe:
+//   * a workgroup owns an ANTENNA-BLOCK PAIR (8 antennas i x 16 antennas j = 128 baseline
+//     slots) x 128 modes, so per staged pixel it needs 24 voltages (384 B) instead of all Nant,
+//     and the left operand of a 16-row MFMA block is one broadcast V_i times 16 different V_j;
+//   * pixels below the horizon at time t have zero voltage (vis_simulator.py:237,272): only the
+//     compacted list of pixels above it is walked (half the sky), an exact saving;
+//   * V and Y tiles of 32 pixels are double-buffered in LDS and filled by LDS-DMA
+//     (global_load_lds_dwordx4) one chunk ahead; the per-lane SOURCE address does the pixel
+//     gather and the bank swizzles (V: pixel k of antenna row r sits at slot (k + r) & 31;
+//     Y: odd pixel rows are rotated by 16 modes), so every LDS read is conflict free.
+// 8 waves = 4 (pairs of i) x 2 (64 modes); wave tile 32 slots x 64 modes, Re and Im
+// accumulated by the same lane (16-B complex stores in the epilogue).
+constexpr int SP_PC = 32;                    // pixels per chunk
+constexpr int SP_NI = 8, SP_NJ = 16;         // antenna block sizes
+constexpr int SP_ROWS = SP_NI + SP_NJ;       // staged antenna rows
+constexpr int SP_MT = 128;                   // modes per workgroup
+constexpr int SP_VBUF = SP_ROWS * SP_PC;     // complex elements per V buffer
+constexpr int SP_YBUF = SP_PC * SP_MT;       // doubles per Y buffer
+
+__global__ void __launch_bounds__(512, 1)
+sh_project_tiled_kernel(const f64x2* __restrict__ V, int nant, int npix,
+                        const int32_t* __restrict__ pixidx, const int32_t* __restrict__ npix_t,
+                        int npix_max, const int32_t* __restrict__ tiles,
+                        const int32_t* __restrict__ bmap, const double* __restrict__ ymap_p, int nmp,
+                        int nm, const double* __restrict__ scale_f, int nt, int f0, int nf_total,
+                        f64x2* __restrict__ out) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  f64x2* s_v = reinterpret_cast<f64x2*>(smem);                                  // [2][24][32]
+  double* s_y = reinterpret_cast<double*>(smem + (size_t)2 * SP_VBUF * 16);     // [2][32][128]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wb = wave >> 1, wn = wave & 1;
+  const int kp = lane >> 4, lc = lane & 15;
+  const int tile = blockIdx.y, n0 = blockIdx.x * SP_MT, ft = blockIdx.z;
+  const int t = ft % nt;
+  const int i0 = tiles[2 * tile], j0 = tiles[2 * tile + 1];
+  const f64x2* vft = V + (size_t)ft * nant * npix;
+  const int32_t* pix = pixidx + (size_t)t * npix_max;
+  const int count = npix_t[t];
+  const int nchunk = (count + SP_PC - 1) / SP_PC;
+
+  // DMA of chunk c into buffer c & 1.  Pieces: 12 for V (two antenna rows each), 32 for Y (one
+  // pixel row each); wave w takes pieces w, w+8, ...
+  auto issue = [&](int c) {
+    int buf = c & 1;
+    int kidx = c * SP_PC + (lane & 31);
+    int mypix = pix[min(kidx, count - 1)];      // lanes l and l+32 hold the same entry
+#pragma unroll
+    for (int it = 0; it < 6; ++it) {
+      int piece = wave + 8 * it;                // 0..47, 44 used
+      if (piece < 12) {
+        int row = 2 * piece + (lane >> 5);
+        int ant = (row < SP_NI) ? i0 + row : j0 + (row - SP_NI);
+        ant = min(ant, nant - 1);
+        int k = ((lane & 31) - row) & 31;        // slot q holds pixel (q - row) & 31
+        int p = __shfl(mypix, k, 64);
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(vft + (size_t)ant * npix + p),
+            (__attribute__((address_space(3))) void*)(s_v + buf * SP_VBUF + piece * 64), 16, 0, 0);
+      } else if (piece < 12 + SP_PC) {
+        int r = piece - 12;
+        int p = __shfl(mypix, r, 64);
+        int src = 2 * ((lane - 8 * (r & 1)) & 63);   // odd rows rotated by 16 modes
+        __builtin_amdgcn_global_load_lds(
+            (const __attribute__((address_space(1))) void*)(ymap_p + (size_t)p * nmp + n0 + src),
+            (__attribute__((address_space(3))) void*)(s_y + buf * SP_YBUF + r * SP_MT), 16, 0, 0);
+      }
+    }
+  };
+
+  f64x4 acc_re[2][4], acc_im[2][4];
+#pragma unroll
+  for (int i = 0; i < 2; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      acc_re[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+      acc_im[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+
+  if (nchunk > 0) issue(0);
+  const int rj = SP_NI + lc;                      // this lane's V_j row
+  for (int c = 0; c < nchunk; ++c) {
+    __syncthreads();                              // chunk c landed; the other buffer is free
+    if (c + 1 < nchunk) issue(c + 1);
+    const f64x2* bv = s_v + (c & 1) * SP_VBUF;
+    const double* by = s_y + (c & 1) * SP_YBUF;
+    const int left = count - c * SP_PC;           // valid pixels in this chunk
+#pragma unroll
+    for (int k = 0; k < SP_PC; k += 4) {
+      int kk = k + kp;
+      double m = (kk < left) ? 1.0 : 0.0;         // tail of the pixel list
+      f64x2 vj = bv[rj * SP_PC + ((kk + rj) & 31)];
+      double are[2], aim[2];
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        int ri = wb * 2 + q;
+        f64x2 vi = bv[ri * SP_PC + ((kk + ri) & 31)];
+        f64x2 r = cmul_conj(vi, vj);
+        are[q] = r.x * m;
+        aim[q] = r.y * m;
+      }
+      const double* yrow = by + kk * SP_MT;
+      int rot = 16 * (kk & 1);
+      double bvv[4];
+#pragma unroll
+      for (int j = 0; j < 4; ++j) bvv[j] = yrow[(wn * 64 + j * 16 + lc + rot) & 127];
+#pragma unroll
+      for (int q = 0; q < 2; ++q)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          acc_re[q][j] = mfma(are[q], bvv[j], acc_re[q][j]);
+          acc_im[q][j] = mfma(aim[q], bvv[j], acc_im[q][j]);
+        }
+    }
+  }
+  // D[(l>>4) + 4g][l&15]: row -> j slot, col -> mode
+  const int f = ft / nt;
+  double sc = scale_f ? scale_f[f] : 1.0;
+  const size_t nft_total = (size_t)nf_total * nt;
+  const size_t ft_out = (size_t)(f0 + f) * nt + t;
+#pragma unroll
+  for (int q = 0; q < 2; ++q)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      int slot = (wb * 2 + q) * SP_NJ + kp + 4 * g;
+      int b = bmap[(size_t)tile * (SP_NI * SP_NJ) + slot];
+      if (b < 0) continue;
+      f64x2* orow = out + ((size_t)b * nft_total + ft_out) * nm;
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        int n = n0 + wn * 64 + j * 16 + lc;
+        if (n < nm) orow[n] = f64x2{acc_re[q][j][g] * sc, acc_im[q][j][g] * sc};
+      }
+    }
+}
+
 }  // namespace hydra
 
 using namespace hydra;
@@ -269,6 +406,31 @@ int hydra_sh_project(const double* V, int nf, int nt, int nant, int npix, const 
       reinterpret_cast<const f64x2*>(V), nf * nt, nant, npix, bl_i, bl_j, nbl, ymap, nm, scale_f, nt,
       reinterpret_cast<f64x2*>(out));
   HYDRA_CHECK_LAUNCH("hydra_sh_project");
+  return HYDRA_OK;
+}
+
+
+int hydra_sh_project_tiled(const double* V, int nf, int nt, int nant, int npix,
+                           const int32_t* pixidx, const int32_t* npix_t, int npix_max,
+                           const int32_t* tiles, const int32_t* bmap, int ntile,
+                           const double* ymap_padded, int nm_padded, int nm, const double* scale_f,
+                           int f0, int nf_total, double* out, void* stream) {
+  HYDRA_CHECK_ARG(V && pixidx && npix_t && tiles && bmap && ymap_padded && out,
+                  "hydra_sh_project_tiled: null pointer argument");
+  HYDRA_CHECK_ARG(nf > 0 && nt > 0 && nant > 0 && npix > 0 && npix_max > 0 && ntile > 0 && nm > 0,
+                  "hydra_sh_project_tiled: sizes must be positive");
+  HYDRA_CHECK_ARG(nm_padded % SP_MT == 0 && nm_padded >= nm,
+                  "hydra_sh_project_tiled: nm_padded must be a multiple of %d and >= nm", SP_MT);
+  HYDRA_CHECK_ARG(f0 >= 0 && f0 + nf <= nf_total, "hydra_sh_project_tiled: channel block out of range");
+  HYDRA_CHECK_ARG((long long)nf * nt <= 65535 && ntile <= 65535,
+                  "hydra_sh_project_tiled: nf*nt and ntile must be <= 65535 per call");
+  size_t lds = (size_t)2 * SP_VBUF * 16 + (size_t)2 * SP_YBUF * 8;
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(&sh_project_tiled_kernel), lds)) return rc;
+  dim3 grid(nm_padded / SP_MT, ntile, nf * nt);
+  sh_project_tiled_kernel<<<grid, 512, lds, as_stream(stream)>>>(
+      reinterpret_cast<const f64x2*>(V), nant, npix, pixidx, npix_t, npix_max, tiles, bmap,
+      ymap_padded, nm_padded, nm, scale_f, nt, f0, nf_total, reinterpret_cast<f64x2*>(out));
+  HYDRA_CHECK_LAUNCH("hydra_sh_project_tiled");
   return HYDRA_OK;
 }
 

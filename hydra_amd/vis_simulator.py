@@ -293,7 +293,9 @@ def sh_mode_maps(lmax, nside, amplitude=1.0, packed=False):
 
 def sh_voltages(nside, ants, freqs, lsts, beams, latitude=DEFAULT_LATITUDE):
     """Voltages of the HEALPix pixels treated as unit-flux sources, with the reference's
-    coordinate convention dec = theta - pi/2, ra = phi (vis_simulator.py:657-664)."""
+    coordinate convention dec = theta - pi/2, ra = phi (vis_simulator.py:657-664).  The tensor
+    carries ``hydra_pixidx`` / ``hydra_npix_t``: per time the indices of the pixels above the
+    horizon (the others have exactly zero voltage, vis_simulator.py:237,272)."""
     theta, phi = healpix_pixel_coords(nside)
     dec = theta - 0.5 * np.pi
     freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
@@ -303,25 +305,93 @@ def sh_voltages(nside, ants, freqs, lsts, beams, latitude=DEFAULT_LATITUDE):
         "The `beams` list must have as many entries as the ``ants`` dict.")
     antpos = np.array([ants[k] for k in ants.keys()], dtype=np.float64)
     crd_eq, eq2tops = _geometry(phi, dec, lsts, latitude)
-    return antenna_voltages(antpos, freqs, eq2tops, crd_eq, fluxes, list(beams))
+    V = antenna_voltages(antpos, freqs, eq2tops, crd_eq, fluxes, list(beams))
+    V.hydra_pixidx, V.hydra_npix_t = _horizon_lists(eq2tops, crd_eq)
+    return V
 
 
-def sh_project(V, bl_i, bl_j, ymap, scale_f=None):
-    """out (Nbl, Nf, Nt, Ncols) = sum_p conj(V_i,p) V_j,p Ymap[p, :] on the matrix cores."""
+def _horizon_lists(eq2tops, crd_eq):
+    """(pixidx (Nt, npix_max) int32, npix_t (Nt) int32): sources with tz > 0 at each time, in
+    ascending order; rows are padded with their last valid entry."""
+    nt, ns = eq2tops.shape[0], crd_eq.shape[1]
+    az = _dev.empty((nt, ns), torch.float64)
+    za = _dev.empty((nt, ns), torch.float64)
+    up = _dev.empty((nt, ns), torch.uint8)
+    _dev.call("hydra_az_za", _dev.ptr(eq2tops), nt, _dev.ptr(crd_eq), ns, _dev.ptr(az),
+              _dev.ptr(za), _dev.ptr(up), _dev.stream_ptr())
+    counts = up.sum(dim=1).to(torch.int32)
+    npix_max = max(int(counts.max().item()), 1)
+    # stable sort puts the flagged sources first, in ascending index order
+    order = torch.argsort(up.to(torch.int16), dim=1, descending=True, stable=True)[:, :npix_max]
+    pos = torch.arange(npix_max, device=up.device)[None, :]
+    last = torch.clamp(counts.long() - 1, min=0)[:, None]
+    pixidx = torch.gather(order, 1, torch.minimum(pos.expand(nt, -1), last))
+    return pixidx.to(torch.int32).contiguous(), counts.contiguous()
+
+
+_SH_TILE_I, _SH_TILE_J = 8, 16
+
+
+def _sh_tiles(bl_i, bl_j, nant):
+    """Antenna-block tiles for ``hydra_sh_project_tiled``: (tiles (ntile,2), bmap (ntile,128))
+    or None if a pair occurs twice (then the untiled kernel is used)."""
+    bl_i = np.asarray(bl_i, dtype=np.int64)
+    bl_j = np.asarray(bl_j, dtype=np.int64)
+    key = bl_i * nant + bl_j
+    if np.unique(key).size != key.size:
+        return None
+    ti, tj = bl_i // _SH_TILE_I, bl_j // _SH_TILE_J
+    nti = (nant + _SH_TILE_I - 1) // _SH_TILE_I
+    tkey = ti * ((nant + _SH_TILE_J - 1) // _SH_TILE_J) + tj
+    uniq, inv = np.unique(tkey, return_inverse=True)
+    ntj = (nant + _SH_TILE_J - 1) // _SH_TILE_J
+    tiles = np.stack([(uniq // ntj) * _SH_TILE_I, (uniq % ntj) * _SH_TILE_J], axis=1).astype(np.int32)
+    bmap = np.full((uniq.size, _SH_TILE_I * _SH_TILE_J), -1, dtype=np.int32)
+    slot = (bl_i - tiles[inv, 0]) * _SH_TILE_J + (bl_j - tiles[inv, 1])
+    bmap[inv, slot] = np.arange(bl_i.size, dtype=np.int32)
+    assert nti > 0
+    return np.ascontiguousarray(tiles), np.ascontiguousarray(bmap)
+
+
+def sh_project(V, bl_i, bl_j, ymap, scale_f=None, out=None, f0=0, nf_total=None):
+    """out (Nbl, Nf, Nt, Ncols) = sum_p conj(V_i,p) V_j,p Ymap[p, :] on the matrix cores.
+
+    With the horizon lists attached by ``sh_voltages`` the tiled kernel is used (antenna-block
+    tiles, only pixels above the horizon); ``out`` / ``f0`` / ``nf_total`` let a caller fill a
+    long frequency axis block by block."""
     nf, nt, nant, npix = V.shape
     bi, bj = _dev.i32(bl_i), _dev.i32(bl_j)
     nbl, nm = bi.numel(), ymap.shape[1]
-    out = _dev.empty((nbl, nf, nt, nm), torch.complex128)
+    nf_total = nf if nf_total is None else int(nf_total)
+    if out is None:
+        out = _dev.empty((nbl, nf_total, nt, nm), torch.complex128)
+    assert tuple(out.shape) == (nbl, nf_total, nt, nm) and out.is_contiguous()
     sc = None if scale_f is None else _dev.f64(scale_f)
-    step = max(1, 65535 // nt)          # grid.z limit: a block of whole channels per launch
-    for f0 in range(0, nf, step):
-        f1 = min(nf, f0 + step)
-        if f0 == 0 and f1 == nf:
-            _dev.call("hydra_sh_project", _dev.ptr(V), nf, nt, nant, npix, _dev.ptr(bi),
-                      _dev.ptr(bj), nbl, _dev.ptr(ymap), nm, _dev.ptr(sc), _dev.ptr(out),
-                      _dev.stream_ptr())
-        else:
-            raise NotImplementedError("more than 65535 (f,t) samples per call")
+    tiles = _sh_tiles(np.asarray(bl_i), np.asarray(bl_j), nant) \
+        if getattr(V, "hydra_pixidx", None) is not None else None
+    if tiles is not None:
+        nmp = (nm + 127) // 128 * 128
+        ymap_p = getattr(ymap, "hydra_padded", None)
+        if ymap_p is None or ymap_p.shape[1] != nmp:
+            ymap_p = torch.zeros((npix, nmp), dtype=torch.float64, device=ymap.device)
+            ymap_p[:, :nm] = ymap
+            ymap.hydra_padded = ymap_p
+        tiles_d, bmap_d = _dev.i32(tiles[0]), _dev.i32(tiles[1])
+        pixidx, npix_t = V.hydra_pixidx, V.hydra_npix_t
+        step = max(1, 65535 // nt)
+        for a in range(0, nf, step):                  # grid.z limit: whole channels per launch
+            b = min(nf, a + step)
+            Vb = V[a:b]
+            _dev.call("hydra_sh_project_tiled", _dev.ptr(Vb), b - a, nt, nant, npix,
+                      _dev.ptr(pixidx), _dev.ptr(npix_t), int(pixidx.shape[1]), _dev.ptr(tiles_d),
+                      _dev.ptr(bmap_d), int(tiles[0].shape[0]), _dev.ptr(ymap_p), nmp, nm,
+                      _dev.ptr(None if sc is None else sc[a:b].contiguous()), f0 + a, nf_total,
+                      _dev.ptr(out), _dev.stream_ptr())
+        return out
+    if nf * nt > 65535 or f0 != 0 or nf_total != nf:
+        raise NotImplementedError("the untiled projection handles one block of <= 65535 (f,t) samples")
+    _dev.call("hydra_sh_project", _dev.ptr(V), nf, nt, nant, npix, _dev.ptr(bi), _dev.ptr(bj), nbl,
+              _dev.ptr(ymap), nm, _dev.ptr(sc), _dev.ptr(out), _dev.stream_ptr())
     return out
 
 

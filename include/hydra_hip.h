@@ -259,6 +259,23 @@ int hydra_sh_project(const double* V, int nf, int nt, int nant, int npix, const 
                      const int32_t* bl_j, int nbl, const double* ymap, int nm,
                      const double* scale_f, double* out, void* stream);
 
+/* The same projection, tiled for the matrix pipe (see csrc/sh.hip): a workgroup owns an
+ * antenna-block pair (8 x 16 antennas = 128 baseline slots) x 128 modes and walks only the
+ * pixels above the horizon at time t.
+ *   pixidx (Nt, npix_max) int32: indices of the pixels with non-zero voltage at time t, first
+ *     npix_t[t] entries valid (vis_simulator.py:237,272 zeroes the others, so skipping them is
+ *     exact); tiles (ntile,2) int32 = first antenna (i0, j0) of the two blocks;
+ *     bmap (ntile,128) int32 = output baseline index of slot (i-i0)*16 + (j-j0), or -1;
+ *   ymap_padded (Npix, nm_padded) f64 with nm_padded a multiple of 128, zero beyond nm;
+ *   out (Nbl, nf_total, Nt, Nm) c128: the channels [f0, f0+nf) are written (V holds nf channels),
+ *   so a long frequency axis can be projected block by block.  Same result as hydra_sh_project
+ *   up to the order of the pixel sum.                vis_simulator.py:702-730; sh_sampler.py:152-168 */
+int hydra_sh_project_tiled(const double* V, int nf, int nt, int nant, int npix,
+                           const int32_t* pixidx, const int32_t* npix_t, int npix_max,
+                           const int32_t* tiles, const int32_t* bmap, int ntile,
+                           const double* ymap_padded, int nm_padded, int nm, const double* scale_f,
+                           int f0, int nf_total, double* out, void* stream);
+
 /* ---- gains ------------------------------------------------------------------------ */
 
 /* v[b,f,t] *= g_i conj(g_j) (1 + x_i + conj(x_j)) in place; pert may be NULL
