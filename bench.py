@@ -45,6 +45,11 @@ CONFIGS = {
     # 19 outriggers on a 300 m ring), gridded beam with bicubic interpolation,
     # baseline-sharded Gram + all-reduce; 8192 sources instead of 100 000, 8 channels x 1 time
     "c5s": ((11, 21), 8192, 8, 1),
+    # c5 = BASELINE config 5 at full source count on ONE GPU's share of the channels: 350 antennas,
+    # 100 000 sources (80 GB Gram), gridded beam; 2 channels x 1 time per step here (the node
+    # target is 128 channels over 8 GPUs = 16 per GPU); CG solve (a dense factorisation of a
+    # 100 000^2 matrix is not what the reference would do either: example.py --solver mpicg)
+    "c5": ((11, 21), 100000, 2, 1),
 }
 SH_CONFIGS = {
     # spherical-harmonic head -- name: (hex_spec, lmax, nside, Nf, Nt)
@@ -479,8 +484,11 @@ def main():
         return main_gain(args, comm, rank, world, dev)
 
     hex_spec, ns, nf, nt = CONFIGS[args.config]
-    big = args.config == "c5s"
-    shard = args.shard or ("baseline" if big else "freq")
+    big = args.config in ("c5s", "c5")
+    shard = args.shard or ("baseline" if args.config == "c5s" else "freq")
+    if args.config == "c5":
+        args.solver = "cg"
+        args.no_cpu = True     # the CPU path cannot form or solve a 100 000^2 system in minutes
     inp = synth_inputs(hex_spec, ns, nf, nt, outriggers=19 if big else 0)
     ant_pos, antpairs_all = inp["ant_pos"], inp["antpairs"]
     nant = len(ant_pos)

@@ -63,6 +63,11 @@ __device__ __forceinline__ void tile_of(int p, int* ti, int* tj) {
 // Block id -> (tile, split) such that blocks with equal id % 8 (which share an XCD and its
 // L2 under round-robin dispatch) work on the same row range one tile after another.
 __device__ __forceinline__ void block_work(int id, int ntiles, int* tile, int* split) {
+  if (gridDim.x == (unsigned)ntiles) {  // one split (many tiles): nothing to interleave
+    *tile = id;
+    *split = 0;
+    return;
+  }
   int xcd = id & 7, q = id >> 3;
   *tile = q % ntiles;
   *split = (q / ntiles) * 8 + xcd;
@@ -279,6 +284,11 @@ static void gram_plan(long long nunits, int ns, int* ntiles, int* nsplit, long l
                       long long unit_align, long long min_units) {
   int nt1 = (ns + TS - 1) / TS;
   *ntiles = nt1 * (nt1 + 1) / 2;
+  if (*ntiles >= 16384) {  // enough tiles to fill the chip evenly: no K split, slabs = the tiles
+    *nsplit = 1;
+    *per_split = (nunits + unit_align - 1) / unit_align * unit_align;
+    return;
+  }
   long long want = std::max<long long>(8, 4096 / *ntiles);
   want = (want + 7) / 8 * 8;
   long long cap = std::max<long long>(8, (nunits / min_units) / 8 * 8);
@@ -726,6 +736,11 @@ gram_finish_k3_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, 
 
 static void k3_plan(long long nft, int ns, int* ntiles, int* nsplit, long long* per) {
   *ntiles = k3_ntiles(ns);
+  if (*ntiles >= 16384) {
+    *nsplit = 1;
+    *per = nft;
+    return;
+  }
   long long want = std::max<long long>(8, 4096 / *ntiles);
   want = (want + 7) / 8 * 8;
   long long cap = std::max<long long>(8, nft / 8 * 8);
