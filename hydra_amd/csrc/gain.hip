@@ -88,6 +88,94 @@ gain_pairs_kernel(const f64x2* __restrict__ g, const double* __restrict__ W,
   }
 }
 
+
+// Tiled form of gain_pairs_kernel for pair lists without duplicates.  A workgroup owns 16
+// antennas x 64 (f,t) samples: lanes <-> (f,t), each wave 4 antennas.  It walks all antennas
+// o in blocks of 16 whose fields g_o (NV vectors) are staged in LDS, so one LDS read of g_o
+// serves 4 antennas, and the only per-pair global traffic is the weight W itself (8 B, 512-B
+// coalesced per wave) -- the CSR kernel re-reads g_o from L2 for every pair and is bound by the
+// vector cache.  pairb[a*nant + o] = baseline of the pair {a,o} or -1; an auto-correlation
+// (a == o) counts twice, as in the adjacency form.  Antenna blocks are the fast grid axis so the
+// two ends of a baseline are read close in time (second read from L2 / MALL).
+template <int NV>
+__global__ void __launch_bounds__(256)
+gain_pairs_tiled_kernel(const f64x2* __restrict__ g, const double* __restrict__ W,
+                        const int32_t* __restrict__ pairb, int nant, int nft, int v0, int nvec,
+                        f64x2* __restrict__ y) {
+  __shared__ f64x2 s_g[16 * NV * 64];   // [o][v][ft lane]
+  __shared__ int32_t s_b[16 * 16];      // [a local][o local] baseline index of the block pair
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ablk = blockIdx.x * 16;
+  const int a0 = ablk + wave * 4;
+  const int ft = blockIdx.y * 64 + lane;
+  const bool ftok = ft < nft;
+  const int ftc = ftok ? ft : nft - 1;
+  double sw[4] = {0.0, 0.0, 0.0, 0.0};
+  f64x2 acc[4][NV];
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+#pragma unroll
+    for (int v = 0; v < NV; ++v) acc[q][v] = f64x2{0.0, 0.0};
+  const double* Wft = W + ftc;
+  for (int o0 = 0; o0 < nant; o0 += 16) {
+    __syncthreads();
+    for (int e = wave; e < 16 * NV; e += 4) {     // e = o_local * NV + v
+      int ol = e / NV, v = e - ol * NV;
+      int o = min(o0 + ol, nant - 1);
+      int vv = min(v0 + v, nvec - 1);
+      s_g[e * 64 + lane] = g[((size_t)vv * nant + o) * nft + ftc];
+    }
+    {   // the 16 x 16 baseline indices of this block pair, one per thread (-1: no such pair)
+      int al = threadIdx.x >> 4, ol = threadIdx.x & 15;
+      int a = ablk + al, o = o0 + ol;
+      s_b[threadIdx.x] = (a < nant && o < nant) ? pairb[(size_t)a * nant + o] : -1;
+    }
+    __syncthreads();
+    // 4 other antennas per trip: their 16 weight loads are issued together
+#pragma unroll
+    for (int ol = 0; ol < 16; ol += 4) {
+      double w[4][4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          int b = s_b[(wave * 4 + q) * 16 + ol + k];            // wave-uniform
+          double wv = (b >= 0) ? Wft[(size_t)b * nft] : 0.0;
+          if (a0 + q == o0 + ol + k) wv *= 2.0;
+          w[k][q] = wv;
+        }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+#pragma unroll
+        for (int q = 0; q < 4; ++q) sw[q] += w[k][q];
+#pragma unroll
+        for (int v = 0; v < NV; ++v) {
+          f64x2 go = s_g[((ol + k) * NV + v) * 64 + lane];
+#pragma unroll
+          for (int q = 0; q < 4; ++q) {
+            acc[q][v].x += w[k][q] * go.x;
+            acc[q][v].y += w[k][q] * go.y;
+          }
+        }
+      }
+    }
+  }
+  if (!ftok) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int a = a0 + q;
+    if (a >= nant) continue;
+#pragma unroll
+    for (int v = 0; v < NV; ++v) {
+      if (v0 + v < nvec) {
+        size_t o = ((size_t)(v0 + v) * nant + a) * nft + ft;
+        f64x2 ga = g[o];
+        y[o] = f64x2{ga.x * sw[q] + acc[q][v].x, ga.y * sw[q] - acc[q][v].y};
+      }
+    }
+  }
+}
+
 // v[b,ft] = (x_i + conj(x_j)) * mv[b,ft]
 __global__ void __launch_bounds__(256)
 gain_proj_kernel(const f64x2* __restrict__ x, const int32_t* __restrict__ bl_i,
@@ -280,6 +368,29 @@ int hydra_gain_basis_adj(const double* y, int nvec, int nant, int nmodes, int nf
       reinterpret_cast<const f64x2*>(y), reinterpret_cast<const f64x2*>(Fbasis), pspec_sqrt, add,
       nant, nmodes, nft, out);
   HYDRA_CHECK_LAUNCH("hydra_gain_basis_adj");
+  return HYDRA_OK;
+}
+
+
+int hydra_gain_pairs_tiled(const double* g, int nvec, int nant, int nft, const double* W, int nbl,
+                           const int32_t* pairb, double* y, void* stream) {
+  HYDRA_CHECK_ARG(g && W && pairb && y, "hydra_gain_pairs_tiled: null pointer");
+  HYDRA_CHECK_ARG(nvec > 0 && nant > 0 && nft > 0 && nbl > 0, "hydra_gain_pairs_tiled: bad sizes");
+  dim3 grid((nant + 15) / 16, (nft + 63) / 64);
+  HYDRA_CHECK_ARG(grid.y <= 65535, "hydra_gain_pairs_tiled: nft too large");
+  hipStream_t st = as_stream(stream);
+  const f64x2* gp = reinterpret_cast<const f64x2*>(g);
+  f64x2* yp = reinterpret_cast<f64x2*>(y);
+  for (int v0 = 0; v0 < nvec; v0 += 4) {
+    int left = nvec - v0;
+    if (left >= 3)
+      gain_pairs_tiled_kernel<4><<<grid, 256, 0, st>>>(gp, W, pairb, nant, nft, v0, nvec, yp);
+    else if (left == 2)
+      gain_pairs_tiled_kernel<2><<<grid, 256, 0, st>>>(gp, W, pairb, nant, nft, v0, nvec, yp);
+    else
+      gain_pairs_tiled_kernel<1><<<grid, 256, 0, st>>>(gp, W, pairb, nant, nft, v0, nvec, yp);
+    HYDRA_CHECK_LAUNCH("hydra_gain_pairs_tiled");
+  }
   return HYDRA_OK;
 }
 

@@ -63,6 +63,20 @@ class _Index:
         self.adj_o = np.ascontiguousarray(other[order], dtype=np.int32)
         self.adj_role = np.ascontiguousarray(role[order], dtype=np.int32)
         self._dev = None
+        # dense pair -> baseline table for the LDS-tiled operator kernel (None if a pair repeats)
+        lo, hi = np.minimum(i1, i2).astype(np.int64), np.maximum(i1, i2).astype(np.int64)
+        self.pair_table = None
+        if np.unique(lo * self.nants + hi).size == nbl:
+            tab = np.full((self.nants, self.nants), -1, dtype=np.int32)
+            tab[lo, hi] = np.arange(nbl, dtype=np.int32)
+            tab[hi, lo] = np.arange(nbl, dtype=np.int32)
+            self.pair_table = np.ascontiguousarray(tab)
+        self._pair_dev = None
+
+    def pair_dev(self):
+        if self._pair_dev is None and self.pair_table is not None:
+            self._pair_dev = _dev.i32(self.pair_table)
+        return self._pair_dev
 
     def dev(self):
         if self._dev is None:
@@ -153,6 +167,8 @@ class GainOperator:
         _dev.call("hydra_gain_weights", _dev.ptr(mv), _dev.ptr(w), self.nbl * self.nft,
                   _dev.ptr(self.W), _dev.stream_ptr())
         self.n = 2 * self.idx.nants * self.nmodes
+        #: use the LDS-tiled pair kernel when the pair list has no duplicates
+        self.tiled = True
 
     def local(self, X, add=None):
         X = _dev.f64(X)
@@ -167,9 +183,14 @@ class GainOperator:
         _dev.call("hydra_gain_basis_fwd", _dev.ptr(Xb), nvec, nants, self.nmodes, nft,
                   _dev.ptr(self.F), _dev.ptr(self.s), _dev.ptr(g), st)
         y = _dev.empty((nvec, nants, nft), torch.complex128)
-        _dev.call("hydra_gain_pairs", _dev.ptr(g), nvec, nants, nft, _dev.ptr(self.W), self.nbl,
-                  _dev.host_ptr(self.idx.adj_ptr), _dev.ptr(adj_ptr), _dev.ptr(adj_b),
-                  _dev.ptr(adj_o), int(self.idx.adj_b.size), _dev.ptr(y), st)
+        pairb = self.idx.pair_dev() if self.tiled else None
+        if pairb is not None:
+            _dev.call("hydra_gain_pairs_tiled", _dev.ptr(g), nvec, nants, nft, _dev.ptr(self.W),
+                      self.nbl, _dev.ptr(pairb), _dev.ptr(y), st)
+        else:
+            _dev.call("hydra_gain_pairs", _dev.ptr(g), nvec, nants, nft, _dev.ptr(self.W),
+                      self.nbl, _dev.host_ptr(self.idx.adj_ptr), _dev.ptr(adj_ptr),
+                      _dev.ptr(adj_b), _dev.ptr(adj_o), int(self.idx.adj_b.size), _dev.ptr(y), st)
         out = _dev.empty((nvec, self.n), torch.float64)
         addb = None if add is None else _dev.f64(add).reshape(nvec, self.n)
         _dev.call("hydra_gain_basis_adj", _dev.ptr(y), nvec, nants, self.nmodes, nft,

@@ -309,6 +309,12 @@ int hydra_gain_pairs(const double* g, int nvec, int nant, int nft, const double*
                      const int32_t* adj_ptr_host, const int32_t* adj_ptr, const int32_t* adj_b,
                      const int32_t* adj_o, int nadj, double* y, void* stream);
 
+/* Same operator for pair lists without duplicates, tiled through LDS (16 antennas x 64 (f,t)
+ * per workgroup; see csrc/gain.hip): pairb (Nant,Nant) int32 = baseline index of the unordered
+ * pair {a,o} (symmetric), -1 if absent; an auto-correlation counts twice.                   */
+int hydra_gain_pairs_tiled(const double* g, int nvec, int nant, int nft, const double* W, int nbl,
+                           const int32_t* pairb, double* y, void* stream);
+
 /* apply_proj: out[b,f,t] = (x_i + conj(x_j)) model_vis[b,f,t]    gain_sampler.py:81-106 */
 int hydra_gain_proj(const double* x, const int32_t* bl_i, const int32_t* bl_j, int nbl,
                     const double* model_vis, int nft, double* out, void* stream);

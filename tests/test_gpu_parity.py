@@ -543,6 +543,9 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
         ref = gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)
         assert relerr(Y[v], ref) < OP_TOL
     assert relerr(op.apply(X[0]), Y[0]) < 1e-14                             # single-vector path
+    op.tiled = False                                                        # CSR adjacency kernel
+    assert relerr(op.apply(X), Y) < 1e-13
+    op.tiled = True
     assert relerr(gs.apply_operator_mpi(None, X[1], w, ps, A_real, A_imag, mv, Fb), Y[1]) < 1e-14
 
     resid = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
@@ -746,3 +749,28 @@ def test_tiled_sh_projection_matches_untiled_kernel(hy):
         Vb.hydra_pixidx, Vb.hydra_npix_t = V.hydra_pixidx, V.hydra_npix_t
         vs.sh_project(Vb, bi, bj, ymap, scale_f=scale[a:b], out=out, f0=a, nf_total=3)
     assert torch.equal(out, tiled)
+
+
+def test_gain_operator_with_autos_and_repeated_pairs(hy):
+    """Pair lists with auto-correlations (count twice in A^H A) go through the LDS-tiled kernel,
+    lists that repeat a pair fall back to the adjacency kernel; both against the oracle."""
+    from oracle import gcr_gain
+    gs = hy.gain_sampler
+    rng = np.random.RandomState(8)
+    nant, nf, nt, nmodes = 21, 5, 13, 3
+    ants = np.arange(nant)
+    base = [(i, j) for i in range(nant) for j in range(i, nant) if (i + 2 * j) % 5]   # incl. autos
+    for pairs, tiled in ((base, True), (base + base[3:9], False)):
+        nbl = len(pairs)
+        Fb = (rng.randn(nmodes, nf, nt) + 1j * rng.randn(nmodes, nf, nt)) / np.sqrt(nf * nt)
+        mv = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+        w = 1.0 + rng.rand(nbl, nf, nt)
+        ps = 0.1 + rng.rand(nmodes)
+        A_real, A_imag = gs.proj_operator(ants, pairs)
+        i1, i2 = gcr_gain.bl_indices(ants, pairs)
+        op = gs.GainOperator(w, ps, A_real, A_imag, mv, Fb)
+        assert (op.idx.pair_table is not None) == tiled
+        X = rng.randn(5, 2 * nant * nmodes)
+        Y = op.apply(X)
+        for v in range(5):
+            assert relerr(Y[v], gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)) < OP_TOL
