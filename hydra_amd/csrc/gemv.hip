@@ -127,12 +127,14 @@ scale_rows_kernel(const f64x2* y, const double* __restrict__ w, long long m, f64
 
 // out[b,ft] = rowmul[b,ft] * sum_s conj(V[ft,i_b,s]) V[ft,j_b,s] x[s]
 // One workgroup per (f,t): voltages staged 64 sources at a time, thread <-> baseline.
+// With seg != NULL (region sums): blockIdx.y = region r, the sum runs over the sources
+// seg[r] <= s < seg[r+1] only and lands in out[(b,ft), r]; x may be NULL (= 1).
 template <int VCH>
 __global__ void __launch_bounds__(256)
 apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
                const double* __restrict__ x, const f64x2* __restrict__ rowmul,
-               f64x2* __restrict__ out, int bl_per_thread) {
+               f64x2* __restrict__ out, const int32_t* __restrict__ seg, int nreg) {
   extern __shared__ __align__(16) unsigned char smem[];
   constexpr int VPAD = VCH + 1;
   constexpr int NSUB = 64 / VCH;  // antennas staged per wave pass
@@ -142,6 +144,7 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   int slane = lane % VCH, sub = lane / VCH;
   const f64x2* vft = V + (size_t)ft * nant * ns;
+  const int s_lo = seg ? seg[blockIdx.y] : 0, s_hi = seg ? seg[blockIdx.y + 1] : ns;
   // up to 8 baselines per thread are accumulated in registers per pass over the sources
   constexpr int MAXB = 8;
   for (int bbase = 0; bbase < nbl; bbase += 256 * MAXB) {
@@ -155,12 +158,12 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
       bi[q] = ok ? bl_i[b] : 0;
       bj[q] = ok ? bl_j[b] : 0;
     }
-    for (int s0 = 0; s0 < ns; s0 += VCH) {
+    for (int s0 = s_lo; s0 < s_hi; s0 += VCH) {
       __syncthreads();
       int s = s0 + slane;
       for (int a = wave * NSUB + sub; a < nant; a += 4 * NSUB)
-        s_v[a * VPAD + slane] = (s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
-      if (tid < VCH) s_x[tid] = (s0 + tid < ns) ? x[s0 + tid] : 0.0;
+        s_v[a * VPAD + slane] = (s < s_hi) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
+      if (tid < VCH) s_x[tid] = (s0 + tid < s_hi) ? (x ? x[s0 + tid] : 1.0) : 0.0;
       __syncthreads();
 #pragma unroll
       for (int q = 0; q < MAXB; ++q) {
@@ -185,11 +188,10 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
         size_t o = (size_t)b * nft + ft;
         f64x2 v = acc[q];
         if (rowmul) v = cmul(rowmul[o], v);
-        out[o] = v;
+        out[seg ? o * nreg + blockIdx.y : o] = v;
       }
     }
   }
-  (void)bl_per_thread;
 }
 
 // (nbl, nft) -> (nft, nbl) complex transpose so a workgroup reads one (f,t) slice contiguously
@@ -347,28 +349,52 @@ int hydra_scale_rows(const double* y, const double* w, long long m, double* z, v
   return HYDRA_OK;
 }
 
+static int launch_apply_V(const char* who, const double* V, int nf, int nt, int nant, int ns,
+                          const int32_t* bl_i, const int32_t* bl_j, int nbl, const double* x,
+                          const double* rowmul, double* out, const int32_t* seg, int nreg,
+                          void* stream) {
+  const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
+  const f64x2* rm = reinterpret_cast<const f64x2*>(rowmul);
+  f64x2* op = reinterpret_cast<f64x2*>(out);
+  size_t lds64 = ((size_t)nant * 65) * 16 + 64 * 8, lds16 = ((size_t)nant * 17) * 16 + 16 * 8;
+  dim3 grid(nf * nt, seg ? nreg : 1);
+  if (lds64 <= 160 * 1024) {
+    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<64>), lds64)) return rc_lds;
+    apply_V_kernel<64><<<grid, 256, lds64, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,
+                                                                nbl, x, rm, op, seg, nreg);
+  } else {
+    HYDRA_CHECK_ARG(lds16 <= 160 * 1024, "%s: nant=%d exceeds the LDS staging limit (600)", who,
+                    nant);
+    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<16>), lds16)) return rc_lds;
+    apply_V_kernel<16><<<grid, 256, lds16, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,
+                                                                nbl, x, rm, op, seg, nreg);
+  }
+  HYDRA_CHECK_LAUNCH(who);
+  return HYDRA_OK;
+}
+
 int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
                   const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
                   double* out, void* stream) {
   HYDRA_CHECK_ARG(V && bl_i && bl_j && x && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
                   "hydra_apply_V: bad arguments");
-  const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
-  const f64x2* rm = reinterpret_cast<const f64x2*>(rowmul);
-  f64x2* op = reinterpret_cast<f64x2*>(out);
-  size_t lds64 = ((size_t)nant * 65) * 16 + 64 * 8, lds16 = ((size_t)nant * 17) * 16 + 16 * 8;
-  if (lds64 <= 160 * 1024) {
-    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<64>), lds64)) return rc_lds;
-    apply_V_kernel<64><<<nf * nt, 256, lds64, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,
-                                                                   nbl, x, rm, op, 0);
-  } else {
-    HYDRA_CHECK_ARG(lds16 <= 160 * 1024, "hydra_apply_V: nant=%d exceeds the LDS staging limit (600)",
-                    nant);
-    if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<16>), lds16)) return rc_lds;
-    apply_V_kernel<16><<<nf * nt, 256, lds16, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,
-                                                                   nbl, x, rm, op, 0);
-  }
-  HYDRA_CHECK_LAUNCH("hydra_apply_V");
-  return HYDRA_OK;
+  return launch_apply_V("hydra_apply_V", V, nf, nt, nant, ns, bl_i, bl_j, nbl, x, rowmul, out,
+                        nullptr, 1, stream);
+}
+
+int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                      const int32_t* bl_j, int nbl, const int32_t* seg_host, const int32_t* seg,
+                      int nreg, double* out, void* stream) {
+  HYDRA_CHECK_ARG(V && bl_i && bl_j && seg_host && seg && out && nf > 0 && nt > 0 && nant > 0 &&
+                      ns > 0 && nbl > 0 && nreg > 0 && nreg <= 65535,
+                  "hydra_vis_regions: bad arguments");
+  HYDRA_CHECK_ARG(seg_host[0] == 0 && seg_host[nreg] == ns,
+                  "hydra_vis_regions: segments must cover sources 0..%d (got %d..%d)", ns,
+                  seg_host[0], seg_host[nreg]);
+  for (int r = 0; r < nreg; ++r)
+    HYDRA_CHECK_ARG(seg_host[r] <= seg_host[r + 1], "hydra_vis_regions: segment %d is reversed", r);
+  return launch_apply_V("hydra_vis_regions", V, nf, nt, nant, ns, bl_i, bl_j, nbl, nullptr, nullptr,
+                        out, seg, nreg, stream);
 }
 
 size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns) {

@@ -25,6 +25,29 @@ gemv_kernel(const double* __restrict__ A, int n, const double* __restrict__ x,
   }
 }
 
+// y[q] (+)= A[q] x[q] for a stack of nb independent (n,n) matrices (blockIdx.y = q): the
+// per-frequency likelihood term of the cosmological-field operator (cosmo_sampler.py:219-221)
+__global__ void __launch_bounds__(256)
+gemv_batched_kernel(const double* __restrict__ A, int n, const double* __restrict__ x,
+                    double* __restrict__ y, int accumulate) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const double* Aq = A + (size_t)blockIdx.y * n * n;
+  const double* xq = x + (size_t)blockIdx.y * n;
+  double* yq = y + (size_t)blockIdx.y * n;
+  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
+    const double* ap = Aq + (size_t)r * n;
+    double s0 = 0.0, s1 = 0.0;
+    int c = lane;
+    for (; c + 64 < n; c += 128) {
+      s0 += ap[c] * xq[c];
+      s1 += ap[c + 64] * xq[c + 64];
+    }
+    if (c < n) s0 += ap[c] * xq[c];
+    double s = wave_sum(s0 + s1);
+    if (lane == 0) yq[r] = accumulate ? yq[r] + s : s;
+  }
+}
+
 // ---------------------------------------------------------------- CG
 
 constexpr int CG_THREADS = 1024;
@@ -407,6 +430,16 @@ int hydra_gemv(const double* A, int n, const double* x, double* y, void* stream)
   int grid = std::min((n + 3) / 4, 4096);
   gemv_kernel<<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y);
   HYDRA_CHECK_LAUNCH("hydra_gemv");
+  return HYDRA_OK;
+}
+
+int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
+                       void* stream) {
+  HYDRA_CHECK_ARG(A && x && y && n > 0 && nb > 0 && nb <= 65535,
+                  "hydra_gemv_batched: bad arguments (n=%d, nb=%d)", n, nb);
+  dim3 grid(std::min((n + 3) / 4, 1024), nb);
+  gemv_batched_kernel<<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y, accumulate);
+  HYDRA_CHECK_LAUNCH("hydra_gemv_batched");
   return HYDRA_OK;
 }
 

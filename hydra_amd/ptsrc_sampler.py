@@ -73,6 +73,15 @@ class FactoredProj:
         #: |V[f,t,a,s]| independent of the antenna (set by the simulator for a single beam model)
         self.same_beam = bool(getattr(V, "hydra_same_beam", False))
 
+    def channel(self, j):
+        """The operator of frequency channel ``j`` alone (a view of V, tables shared) -- for
+        heads whose channels do not talk to each other (cosmo_sampler.py:276-284)."""
+        sub = object.__new__(FactoredProj)
+        sub.__dict__.update(self.__dict__)
+        sub.V = self.V[j:j + 1]
+        sub.shape = (self.shape[0], 1) + tuple(self.shape[2:])
+        return sub
+
     @property
     def nbytes_materialised(self):
         return int(np.prod(self.shape)) * 16

@@ -102,6 +102,15 @@ int hydra_vis_subarr(const double* V, int nf, int nt, int nant, int ns, int suba
  * (simulate_vis)                                                vis_simulator.py:565-568 */
 int hydra_vis_sum(const double* V, int nf, int nt, int nant, int ns, double* vis, void* stream);
 
+/* Sum over the sources of each region: out (Nbl,Nf,Nt,Nreg) c128,
+ *   out[b,f,t,r] = sum_{seg[r] <= s < seg[r+1]} conj(V[f,t,i_b,s]) V[f,t,j_b,s]
+ * (one simulate_vis per region + baseline gather, region_sampler.py:198-223).  The sources must be
+ * ordered by region; seg (Nreg+1) int32 with seg[0] = 0, seg[Nreg] = Ns is passed twice: a host
+ * copy (validated before launch) and the device copy.                                         */
+int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                      const int32_t* bl_j, int nbl, const int32_t* seg_host, const int32_t* seg,
+                      int nreg, double* out, void* stream);
+
 /* ---- GCR operator ---------------------------------------------------------------- */
 
 /* Per-row factors for rows r = (b,f,t) in (Nbl,Nf,Nt) order:
@@ -212,6 +221,12 @@ int hydra_scale_rows(const double* y, const double* w, long long m, double* z, v
 
 /* y = A x, A (N,N) f64 row-major                                  linear_solver.py:431 */
 int hydra_gemv(const double* A, int n, const double* x, double* y, void* stream);
+
+/* y[q] = A[q] x[q] (accumulate == 0) or y[q] += A[q] x[q], q < nb: A (nb,N,N), x, y (nb,N) f64 --
+ * the per-frequency likelihood term of the cosmological-field operator, added to the prior term
+ * already in y                                                   cosmo_sampler.py:219-221 */
+int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
+                       void* stream);
 
 /* Conjugate gradients exactly as linear_solver.cg (linear_solver.py:378-509):
  * convergence tested BEFORE each iteration, element-wise |r_i| < tol or ||r||_2 < tol.

@@ -1,0 +1,270 @@
+"""
+GPU parity tests of the cosmological-field and diffuse-region heads: the HIP
+path through the hydra_amd API mirror against golden vectors produced by the reference's own
+``cosmo_sampler`` / ``region_sampler`` functions (tests/golden/make_golden_cosmo.py) and against
+the CPU oracle on seeded inputs.
+
+Tolerances as in test_gpu_parity.py: operator entries <= 1e-10, samples <= 1e-8 (relative =
+max|a-b| / max|b|).
+"""
+import argparse
+
+import numpy as np
+import pytest
+
+from conftest import load_golden, relerr
+
+pytestmark = pytest.mark.gpu
+
+OP_TOL = 1e-10
+SAMPLE_TOL = 1e-8
+LAT = -30.7215 * np.pi / 180.0
+
+
+@pytest.fixture(scope="module")
+def hy():
+    import torch
+    assert torch.cuda.is_available(), "GPU tests need a HIP device"
+    import hydra_amd
+    return hydra_amd
+
+
+def _pairs(arr):
+    return [tuple(int(x) for x in p) for p in arr]
+
+
+# ------------------------------------------------------------------ cosmological field
+
+def test_cosmo_setup_functions_match_reference_golden(hy):
+    cs = hy.cosmo_sampler
+    g = load_golden("cosmo.npz")
+    args = argparse.Namespace(cosmo_field_ra_bounds=(10.0, 16.0),
+                              cosmo_field_dec_bounds=(-33.0, -28.0),
+                              cosmo_field_ra_ngrid=5, cosmo_field_dec_ngrid=4)
+    ra, dec = cs.make_cosmo_field_grid(args)
+    assert np.array_equal(ra, g["g_ra"]) and np.array_equal(dec, g["g_dec"])
+    Hz, dAc = cs.calculate_cosmo_fns(h=0.69, omega_m=0.31)
+    assert np.array_equal(Hz(g["zs"]), g["hz"]) and np.array_equal(dAc(g["zs"]), g["r"])
+    x, y = np.unique(ra), np.unique(dec)
+    kx, ky, knu = cs.comoving_fourier_modes(x=x, y=y, freqs=g["freqs"], h=0.69, omega_m=0.31)
+    assert np.array_equal(kx, g["kx"]) and np.array_equal(ky, g["ky"])
+    assert np.array_equal(knu, g["knu"])
+    p3 = cs.calculate_pspec_on_grid(kbins=g["kbins"], pspec=g["pk"], x=x, y=y, freqs=g["freqs"],
+                                    h=0.69, omega_m=0.31)
+    assert np.array_equal(p3, g["pspec3d"])
+
+
+def test_cosmo_prior_and_operator_match_reference_golden(hy):
+    cs = hy.cosmo_sampler
+    g = load_golden("cosmo.npz")
+    for key, ex in [("s_plus", 1), ("s_inv", -1.0), ("s_mhalf", -0.5)]:
+        out = cs.apply_S(g["cube"], g["pspec3d"], exponent=ex)
+        assert isinstance(out, np.ndarray) and out.shape == g["cube"].shape
+        assert relerr(out, g[key]) < 1e-13
+    lhs = cs.apply_lhs_operator(g["xvec"], g["op"], g["pspec3d"])
+    assert lhs.shape == g["lhs"].shape
+    assert relerr(lhs, g["lhs"]) < 1e-13
+
+
+def test_cosmo_precompute_matches_reference_golden(hy):
+    cs = hy.cosmo_sampler
+    g = load_golden("cosmo.npz")
+    ap = _pairs(g["antpairs"])
+    op, rhs = cs.precompute_mpi(None, g["ants"], ap, g["freqs"], g["freqs"], g["times"],
+                                g["proj"], g["data"], g["inv_noise"], g["gains"], g["pspec3d"],
+                                omega_n=g["omega_n"], omega_s=g["omega_s"])
+    assert op.shape == g["op"].shape and rhs.shape == g["rhs"].shape
+    for f in range(op.shape[0]):
+        assert relerr(op[f], g["op"][f]) < OP_TOL
+    assert relerr(rhs, g["rhs"]) < OP_TOL
+    # fluctuation vectors drawn inside, in the reference's order
+    np.random.seed(int(g["seed"]))
+    _, rhs2 = cs.precompute_mpi(None, g["ants"], ap, g["freqs"], g["freqs"], g["times"],
+                                g["proj"], g["data"], g["inv_noise"], g["gains"], g["pspec3d"])
+    assert relerr(rhs2, g["rhs"]) < OP_TOL
+    op0, rhs0 = cs.precompute_mpi(None, g["ants"], ap, g["freqs"], g["freqs"], g["times"],
+                                  g["proj"], g["data"], g["inv_noise"], g["gains"], g["pspec3d"],
+                                  realisation=False)
+    assert relerr(op0, g["op0"]) < OP_TOL and relerr(rhs0, g["rhs0"]) < OP_TOL
+    sl = slice(2, 5)      # a rank that holds channels 2..4 of the grid only
+    opp, rhsp = cs.precompute_mpi(None, g["ants"], ap, g["freqs"], g["freqs"][sl], g["times"],
+                                  g["proj"][:, sl], g["data"][:, sl], g["inv_noise"][:, sl],
+                                  g["gains"][:, sl], g["pspec3d"], realisation=False)
+    assert relerr(opp, g["op_part"]) < OP_TOL and relerr(rhsp, g["rhs_part"]) < OP_TOL
+    assert not opp[0].any() and not opp[5].any()
+
+
+@pytest.mark.parametrize("uniform_noise", [False, True])
+def test_cosmo_head_factored_operator_and_cg_sample(hy, uniform_noise):
+    """The whole head as the driver runs it (example.py:545-556,780-828): grid pixels as unit-flux
+    sources, factored operator, per-channel Grams, CG on the FFT-prior operator -- against the
+    oracle with the same injected fluctuation vectors."""
+    import torch
+    from oracle import beams as obeams, cg as ocg, gcr_cosmo as oc, gcr_ptsrc as op_, helpers
+    cs, ps, ls = hy.cosmo_sampler, hy.ptsrc_sampler, hy.linear_solver
+    rng = np.random.RandomState(7)
+    ant_pos = helpers.build_hex_array(hex_spec=(3, 4), d=14.6)
+    nant = len(ant_pos)
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    nbl = len(antpairs)
+    freqs = np.linspace(100.0, 103.0, 4)
+    times = np.linspace(0.2, 0.5, 5)
+    g_ra, g_dec = oc.field_grid((20.0, 32.0), (-36.0, -26.0), 6, 5)
+    npix = g_ra.size
+    flux = np.ones((npix, freqs.size))
+    x, y = np.unique(g_ra), np.unique(g_dec)
+    kbins = np.linspace(0.0, 10.0, 25)
+    pspec3d = oc.pspec_on_grid(kbins, 0.1 * kbins + 1.0, x, y, freqs, h=0.69, omega_m=0.31)
+    assert pspec3d.shape == (freqs.size, x.size, y.size)
+
+    proj_o = op_.calc_proj_operator(g_ra, g_dec, flux, ant_pos, antpairs, freqs, times,
+                                    [obeams.GaussianBeam(14.0) for _ in range(nant)], LAT)
+    proj_f = ps.calc_proj_operator(g_ra, g_dec, flux, ant_pos, antpairs, freqs, times,
+                                   [hy.beams.GaussianBeam(14.0) for _ in range(nant)], LAT,
+                                   materialize=False)
+    gains = (1.0 + 1.0j) + 0.05 * (rng.randn(nant, 1, 1) + 1j * rng.randn(nant, 1, 1))
+    gains = gains * np.ones((nant, freqs.size, times.size))
+    if uniform_noise:
+        inv_noise = np.full((nbl, freqs.size, times.size), 400.0)
+    else:
+        inv_noise = rng.uniform(100.0, 400.0, size=(nbl, freqs.size, times.size))
+    field = rng.randn(freqs.size, npix) * 0.5
+    model = np.einsum("bftp,fp->bft", proj_o, field)
+    data = helpers.apply_gains(model, gains, ants, antpairs)
+    data = data + 0.05 * (rng.randn(*data.shape) + 1j * rng.randn(*data.shape))
+    omega_n = (rng.randn(*data.shape) + 1j * rng.randn(*data.shape)) / np.sqrt(2.0)
+    omega_s = rng.randn(*pspec3d.shape)
+
+    op_ref, rhs_ref = oc.precompute(ants, antpairs, freqs, freqs, proj_o, data, inv_noise, gains,
+                                    pspec3d, omega_n=omega_n, omega_s=omega_s)
+    op, rhs = cs.precompute_mpi(None, ants, antpairs, freqs, freqs, times, proj_f, data,
+                                inv_noise, gains, pspec3d, omega_n=omega_n, omega_s=omega_s)
+    want = "gram_uniform_kernel" if uniform_noise else "gram_fused_kernel"
+    assert proj_f.channel(0).complete
+    for f in range(freqs.size):
+        assert relerr(op[f], op_ref[f]) < OP_TOL
+    assert relerr(rhs, rhs_ref) < OP_TOL
+    sub = proj_f.channel(1)
+    sub.gram(torch.as_tensor(gains[:, 1:2]).cuda().contiguous(),
+             torch.as_tensor(inv_noise[:, 1:2]).cuda().contiguous())
+    assert sub.last_gram_kernel == want
+
+    shape3 = pspec3d.shape
+    x_ref = ocg.cg(None, rhs_ref.flatten(), maxiters=2000, abs_tol=1e-10,
+                   linear_op=lambda v: oc.apply_lhs_operator(v.reshape(shape3), op_ref,
+                                                             pspec3d).flatten())
+    opd, p3d = torch.as_tensor(op).cuda(), torch.as_tensor(pspec3d).cuda()
+    x_gpu = ls.cg(Amat=None, bvec=torch.as_tensor(rhs).cuda().flatten(), maxiters=2000, abs_tol=1e-10,
+                  linear_op=lambda v: cs.apply_lhs_operator(v.reshape(shape3), opd, p3d).flatten())
+    assert x_gpu.is_cuda
+    x_gpu = x_gpu.cpu().numpy()
+    x_np = ls.cg(Amat=None, bvec=rhs.flatten(), maxiters=2000, abs_tol=1e-10,
+                 linear_op=lambda v: cs.apply_lhs_operator(v.reshape(shape3), op, pspec3d).flatten())
+    assert isinstance(x_np, np.ndarray) and relerr(x_np, x_ref) < SAMPLE_TOL
+    assert relerr(x_gpu, x_ref) < SAMPLE_TOL
+    res = oc.apply_lhs_operator(x_gpu.reshape(shape3), op_ref, pspec3d).flatten() - rhs_ref.flatten()
+    assert np.abs(res).max() / np.abs(rhs_ref).max() < SAMPLE_TOL
+
+
+# ------------------------------------------------------------------ diffuse regions
+
+def test_region_segmentation_matches_reference_golden(hy):
+    rs = hy.region_sampler
+    g = load_golden("region_segments.npz")
+    for nreg in (3, 8):
+        idx = rs.segmented_diffuse_sky_model_pixels(g["ra"], g["dec"], g["sky"], g["freqs"], nreg)
+        assert len(idx) == int(g[f"n{nreg}_count"])
+        for q, ix in enumerate(idx):
+            assert np.array_equal(ix, g[f"n{nreg}_{q}"])
+    with pytest.raises(NotImplementedError):
+        rs.segmented_diffuse_sky_model_pixels(g["ra"], g["dec"], g["sky"], g["freqs"], 3,
+                                              smoothing_fwhm=2.0)
+    with pytest.raises(NotImplementedError):
+        rs.get_diffuse_sky_model_pixels(g["freqs"])
+
+
+@pytest.mark.parametrize("hex_spec,npx,nreg,nf,nt", [((3, 4), 150, 4, 3, 4), ((2, 3), 70, 1, 2, 3),
+                                                    ((4, 7), 333, 7, 2, 2)])
+def test_region_proj_operator_matches_oracle(hy, hex_spec, npx, nreg, nf, nt):
+    from oracle import beams as obeams, gcr_region, helpers
+    rs = hy.region_sampler
+    rng = np.random.RandomState(nreg)
+    ant_pos = helpers.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    ra = rng.uniform(0.0, 2.0 * np.pi, npx)          # whole sky: most pixels below the horizon
+    dec = np.arcsin(rng.uniform(-1.0, 1.0, npx))
+    beta = rng.uniform(-3.0, -2.2, npx)
+    sky = rng.uniform(1.0, 50.0, npx)[:, None] * (freqs[None, :] / 100.0) ** beta[:, None]
+    if nreg > 1:
+        idxs = gcr_region.segment_pixels(ra, dec, sky, freqs, nreg)
+    else:
+        idxs = [np.arange(npx)]                        # example.py:269: one region = whole map
+    ref = gcr_region.calc_proj_operator(ra, dec, sky, idxs, ant_pos, antpairs, freqs, times,
+                                        [obeams.GaussianBeam(14.0) for _ in range(nant)], LAT)
+    out = rs.calc_proj_operator(region_pixel_ra=ra, region_pixel_dec=dec, region_fluxes=sky,
+                                region_idxs=idxs, ant_pos=ant_pos, antpairs=antpairs,
+                                freqs=freqs, times=times,
+                                beams=[hy.beams.GaussianBeam(14.0) for _ in range(nant)],
+                                latitude=LAT)
+    assert isinstance(out, np.ndarray) and out.shape == ref.shape
+    assert out.shape == (len(antpairs), nf, nt, len(idxs))
+    assert relerr(out, ref) < OP_TOL
+
+
+def test_region_operator_edge_cases_and_joint_system(hy):
+    """Empty region, overlapping regions, a reversed antenna pair; then the driver's joint
+    point-source + region system (example.py:526-533,878-889) against the oracle."""
+    from oracle import beams as obeams, gcr_ptsrc, gcr_region, helpers
+    rs, ps = hy.region_sampler, hy.ptsrc_sampler
+    rng = np.random.RandomState(3)
+    ant_pos = helpers.build_hex_array(hex_spec=(3, 4), d=14.6)
+    nant = len(ant_pos)
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    freqs = np.linspace(100.0, 110.0, 3)
+    times = np.linspace(0.2, 0.5, 4)
+    npx = 90
+    ra = rng.uniform(0.0, 1.2, npx)
+    dec = rng.uniform(-0.9, -0.1, npx)
+    sky = rng.uniform(0.5, 5.0, (npx, 1)) * (freqs[None, :] / 100.0) ** -2.5
+    idxs = [np.arange(0, 40), np.array([], dtype=int), np.arange(30, 90), np.array([5])]
+    ob = [obeams.GaussianBeam(14.0) for _ in range(nant)]
+    hb = [hy.beams.GaussianBeam(14.0) for _ in range(nant)]
+    odd_pairs = list(antpairs)
+    odd_pairs[3] = (odd_pairs[3][1], odd_pairs[3][0])      # idx1 > idx2: zeros, as in the reference
+    ref = gcr_region.calc_proj_operator(ra, dec, sky, idxs, ant_pos, odd_pairs, freqs, times, ob, LAT)
+    out = rs.calc_proj_operator(ra, dec, sky, idxs, ant_pos, odd_pairs, freqs, times, hb, LAT)
+    assert relerr(out, ref) < OP_TOL
+    assert not out[..., 1].any() and not out[3].any()
+
+    # joint system: 12 point sources + the non-empty regions
+    keep = [idxs[0], idxs[2]]
+    r_ref = gcr_region.calc_proj_operator(ra, dec, sky, keep, ant_pos, antpairs, freqs, times, ob, LAT)
+    r_out = rs.calc_proj_operator(ra, dec, sky, keep, ant_pos, antpairs, freqs, times, hb, LAT)
+    np.random.seed(2)
+    pra, pdec, amps = helpers.generate_random_ptsrc_catalogue(12, (0.0, 1.0), (-0.6, 0.4))
+    pflux = helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    p_ref = gcr_ptsrc.calc_proj_operator(pra, pdec, pflux, ant_pos, antpairs, freqs, times, ob, LAT)
+    p_out = ps.calc_proj_operator(pra, pdec, pflux, ant_pos, antpairs, freqs, times, hb, LAT)
+    proj_ref = np.concatenate((p_ref, r_ref), axis=-1)
+    proj_out = np.concatenate((p_out, r_out), axis=-1)
+    nsrc = proj_ref.shape[-1]
+    prior = np.concatenate((0.1 * np.ones(12), 0.3 * np.ones(2)))
+    gains = (1.0 + 1.0j) + 0.05 * (rng.randn(nant, 3, 4) + 1j * rng.randn(nant, 3, 4))
+    inv_noise = rng.uniform(50.0, 400.0, size=proj_ref.shape[:3])
+    truth = 1.0 + 0.1 * rng.randn(nsrc)
+    data = helpers.apply_gains((proj_ref.reshape(-1, nsrc) @ truth).reshape(proj_ref.shape[:3]),
+                               gains, ants, antpairs)
+    om_n = (rng.randn(*data.shape) + 1j * rng.randn(*data.shape)) / np.sqrt(2.0)
+    om_a = rng.randn(nsrc)
+    A_ref, b_ref = gcr_ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
+                                        omega_n=om_n, omega_a=om_a)
+    A, b = ps.precompute_mpi(None, ants, antpairs, freqs, times, proj_out, data, inv_noise, gains,
+                             prior, omega_n=om_n, omega_a=om_a)
+    assert relerr(A, A_ref) < OP_TOL and relerr(b, b_ref) < OP_TOL
+    x = hy.linear_solver.solve_dense(A, b)
+    assert relerr(np.asarray(x), gcr_ptsrc.dense_solve(A_ref, b_ref)) < SAMPLE_TOL

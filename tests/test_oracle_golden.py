@@ -168,3 +168,58 @@ def test_gain_operator_matches_reference():
     b = gcr_gain.construct_rhs(g["resid"], g["inv_noise"], g["ps_sqrt"], i1, i2, g["mv"],
                                g["Fb"], om_y, om_r)
     assert relerr(b, g["bvec"]) < TIGHT
+
+
+# ---------------------------------------------------------------- cosmo / region heads
+
+def test_cosmo_grid_modes_and_prior_match_reference():
+    from oracle import gcr_cosmo as oc
+    g = load_golden("cosmo.npz")
+    ra, dec = oc.field_grid((10.0, 16.0), (-33.0, -28.0), 5, 4)
+    assert np.array_equal(ra, g["g_ra"]) and np.array_equal(dec, g["g_dec"])
+    hz_fn, r_fn = oc.background(h=0.69, omega_m=0.31)
+    assert np.array_equal(hz_fn(g["zs"]), g["hz"]) and np.array_equal(r_fn(g["zs"]), g["r"])
+    x, y = np.unique(ra), np.unique(dec)
+    kx, ky, knu = oc.fourier_modes(x, y, g["freqs"], h=0.69, omega_m=0.31)
+    assert np.array_equal(kx, g["kx"]) and np.array_equal(ky, g["ky"])
+    assert np.array_equal(knu, g["knu"])
+    p3 = oc.pspec_on_grid(g["kbins"], g["pk"], x, y, g["freqs"], h=0.69, omega_m=0.31)
+    assert np.array_equal(p3, g["pspec3d"])
+    assert p3.shape == (g["freqs"].size, x.size, y.size)
+    for key, ex in [("s_plus", 1), ("s_inv", -1.0), ("s_mhalf", -0.5)]:
+        assert np.array_equal(oc.apply_S(g["cube"], p3, exponent=ex), g[key])
+    assert np.array_equal(oc.apply_lhs_operator(g["xvec"], g["op"], p3), g["lhs"])
+
+
+def test_cosmo_precompute_matches_reference():
+    from oracle import gcr_cosmo as oc
+    g = load_golden("cosmo.npz")
+    ap = _pairs(g["antpairs"])
+    args = (g["ants"], ap, g["freqs"])
+    op, rhs = oc.precompute(*args, g["freqs"], g["proj"], g["data"], g["inv_noise"], g["gains"],
+                            g["pspec3d"], omega_n=g["omega_n"], omega_s=g["omega_s"])
+    assert relerr(op, g["op"]) < TIGHT and relerr(rhs, g["rhs"]) < TIGHT
+    np.random.seed(int(g["seed"]))          # draws in the reference's order
+    op, rhs = oc.precompute(*args, g["freqs"], g["proj"], g["data"], g["inv_noise"], g["gains"],
+                            g["pspec3d"])
+    assert relerr(rhs, g["rhs"]) < TIGHT
+    op0, rhs0 = oc.precompute(*args, g["freqs"], g["proj"], g["data"], g["inv_noise"], g["gains"],
+                              g["pspec3d"], realisation=False)
+    assert relerr(op0, g["op0"]) < TIGHT and relerr(rhs0, g["rhs0"]) < TIGHT
+    sl = slice(2, 5)                        # a rank holding channels 2..4 only
+    opp, rhsp = oc.precompute(*args, g["freqs"][sl], g["proj"][:, sl], g["data"][:, sl],
+                              g["inv_noise"][:, sl], g["gains"][:, sl], g["pspec3d"],
+                              realisation=False)
+    assert relerr(opp, g["op_part"]) < TIGHT and relerr(rhsp, g["rhs_part"]) < TIGHT
+    assert not opp[0].any() and not opp[5].any()
+
+
+def test_region_segmentation_matches_reference():
+    from oracle import gcr_region
+    g = load_golden("region_segments.npz")
+    for nreg in (3, 8):
+        idx = gcr_region.segment_pixels(g["ra"], g["dec"], g["sky"], g["freqs"], nreg)
+        assert len(idx) == int(g[f"n{nreg}_count"])
+        for q, ix in enumerate(idx):
+            assert np.array_equal(ix, g[f"n{nreg}_{q}"])
+        assert sum(ix.size for ix in idx) == g["ra"].size
