@@ -67,6 +67,17 @@ GAIN_CONFIGS = {
 }
 
 
+COSMO_CONFIGS = {
+    # cosmological-field head -- name: (hex_spec, RA grid, Dec grid, Nf, Nt, sigma)
+    # the c2 array and (f,t) grid with a 32 x 32 field grid: 64 per-channel Grams of 1024^2,
+    # CG on the (S^-1 + blockdiag G_f) operator over 65 536 unknowns.  The field is faint: the
+    # noise level (in units of the unit-flux pixels) is set so that the reference's
+    # unpreconditioned CG converges within its 1000-iteration default (linear_solver.py:378).
+    "cosmo": ((4, 7), 32, 32, 64, 200, 10.0),
+    "cosmos": ((3, 4), 8, 6, 8, 10, 2.0),
+}
+
+
 def synth_inputs(hex_spec, ns, nf, nt, outriggers=0):
     """Synthetic inputs of SURVEY section 8(d): hex array (14.6 m), random catalogue seed 0,
     100-120 MHz, LST 0.2-0.5 rad, Gaussian beam D = 14 m, gains (1+1j) + 0.05 N(0,1),
@@ -451,12 +462,172 @@ def main_gain(args, comm, rank, world, dev):
     print(json.dumps(out))
 
 
+def main_cosmo(args, comm, rank, world, dev):
+    """GCR samples/s of the cosmological-field head (example.py:751-851): per sample the
+    per-channel likelihood blocks and right-hand side (cosmo_sampler.precompute_mpi, factored
+    operator, frequency channels sharded over ranks, summed to the root) and the root's CG solve
+    with the FFT prior + batched block matvec operator."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import cosmo_sampler as cs, ptsrc_sampler
+    hex_spec, n_ra, n_dec, nf, nt, sigma = COSMO_CONFIGS[args.config]
+    ant_pos = hy.utils.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    nbl = len(antpairs)
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    fidx = np.array_split(np.arange(nf), world)[rank]
+    nf_loc = fidx.size
+    gargs = argparse.Namespace(cosmo_field_ra_bounds=(0.0, 60.0), cosmo_field_dec_bounds=(-40.0, -20.0),
+                               cosmo_field_ra_ngrid=n_ra, cosmo_field_dec_ngrid=n_dec)
+    g_ra, g_dec = cs.make_cosmo_field_grid(gargs)
+    npix = g_ra.size
+    gx, gy = np.unique(g_ra), np.unique(g_dec)
+    kbins = np.linspace(0.0, 10.0, 25)
+    pspec3d = cs.calculate_pspec_on_grid(kbins=kbins, pspec=0.1 * kbins + 1.0, x=gx, y=gy,
+                                         freqs=freqs, h=0.69, omega_m=0.31)
+    shape3 = pspec3d.shape
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    lat = -30.7215 * np.pi / 180.0
+    fac = ptsrc_sampler.calc_proj_operator(g_ra, g_dec, np.ones((npix, nf_loc)), ant_pos, antpairs,
+                                           freqs[fidx], times, beams, lat, materialize=False)
+    g0 = (1.0 + 1.0j) + 0.05 * (np.random.RandomState(2).randn(nant)
+                                + 1j * np.random.RandomState(3).randn(nant))
+    gains = torch.as_tensor(g0, device=dev)[:, None, None].expand(nant, nf_loc, nt).contiguous()
+    gen = torch.Generator(device=dev)
+    gen.manual_seed(99 + rank)
+    field = 0.3 * np.random.RandomState(5).randn(nf, npix)
+    data = torch.empty((nbl, nf_loc, nt), dtype=torch.complex128, device=dev)
+    for j in range(nf_loc):
+        data[:, j:j + 1] = fac.channel(j).apply(torch.as_tensor(field[fidx[j]], device=dev))
+    data = hy.utils.apply_gains(data, gains, ants, antpairs, inline=False)
+    data = data + sigma * torch.randn(data.shape, dtype=torch.complex128, device=dev, generator=gen)
+    inv_noise = torch.full((nbl, nf_loc, nt), 1.0 / sigma ** 2, dtype=torch.float64, device=dev)
+    p3d = torch.as_tensor(pspec3d, device=dev)
+    m_loc, m_all = nbl * nf_loc * nt, nbl * nf * nt
+
+    def one_sample():
+        om_n = torch.randn((nbl, nf_loc, nt), dtype=torch.complex128, device=dev, generator=gen)
+        om_s = torch.randn(shape3, dtype=torch.float64, device=dev, generator=gen)
+        op, rhs = cs.precompute_mpi(comm, ants, antpairs, freqs, freqs[fidx], times, fac, data,
+                                    inv_noise, gains, p3d, omega_n=om_n, omega_s=om_s)
+        x, iters = None, 0
+        if rank == 0:
+            x, iters = hy.linear_solver.cg(
+                Amat=None, bvec=rhs.flatten(), maxiters=1000, abs_tol=args.cg_tol, return_iters=True,
+                linear_op=lambda v: cs.apply_lhs_operator(v.reshape(shape3), op, p3d).flatten())
+        return op, rhs, x, iters
+
+    def sync():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_sample()
+    ptsrc_sampler.GRAM_EVENTS = []
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        op, rhs, x, iters = one_sample()
+    sync()
+    elapsed = time.perf_counter() - t0
+    events = ptsrc_sampler.GRAM_EVENTS
+    ptsrc_sampler.GRAM_EVENTS = None
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if comm is not None:
+        comm.allreduce_(t_all, op="max")
+    elapsed = float(t_all.item())
+    gram_ms = float(np.mean([s.elapsed_time(e) for s, e in events])) if events else float("nan")
+    if rank != 0:
+        return
+    lhs = cs.apply_lhs_operator(x.reshape(shape3), op, p3d).flatten()
+    resid = float((torch.linalg.norm(lhs - rhs.flatten()) / torch.linalg.norm(rhs)).item())
+    # one launch = one channel's Gram (Nt samples): flop counts as in main()
+    kernel = getattr(fac, "last_gram_kernel", "gram_fused_kernel")
+    base_flops = 2.0 * (nbl * nt) * npix * (npix + 1)
+    if kernel == "gram_uniform_kernel":
+        per_elem = (6.0 * nant + 10.0) if fac.same_beam else (8.0 * nant + 8.0)
+        gram_flops = nt * 0.5 * npix * (npix + 1) * per_elem
+    else:
+        gram_flops = base_flops
+    achieved = gram_flops / (gram_ms * 1e-3) / 1e12
+    out = {
+        "metric": "GCR samples/sec (cosmo field head, whole job)",
+        "value": args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"cosmological-field GCR ({args.config}): hex{hex_spec} = {nant} antennas / "
+                         f"{nbl} baselines, {n_ra} x {n_dec} field grid = {npix} pixels per channel, "
+                         f"{nf} freqs x {nt} times ({nf * npix} unknowns), noise sigma {sigma}, factored operator, "
+                         f"per-channel Grams + CG with FFT prior, complex128"),
+            "rows_M": m_all, "solver": "cg", "cg_abs_tol": args.cg_tol, "cg_iters_last": int(iters),
+            "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
+        },
+        "gram_tflops_whole_job": world * base_flops / (gram_ms * 1e-3) / 1e12,
+        "sample_rel_residual": resid,
+        "roofline": {
+            "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
+            "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "kernel": kernel + " (one channel per launch)", "ms_per_launch": gram_ms,
+            "flops_per_launch": gram_flops,
+        },
+        "cpu_baseline": None,
+    }
+    if not args.no_cpu:
+        out["cpu_baseline"] = cosmo_cpu_baseline(ant_pos, antpairs, freqs, times, g_ra, g_dec, g0,
+                                                 sigma, pspec3d, op.cpu().numpy(), int(iters), m_all)
+    print(json.dumps(out))
+
+
+def cosmo_cpu_baseline(ant_pos, antpairs, freqs, times, g_ra, g_dec, g0, sigma, pspec3d, op_full,
+                       iters, full_rows):
+    """The oracle (numpy restatement of cosmo_sampler.precompute_mpi + linear_solver.cg with
+    apply_lhs_operator) on this host: precompute on a 1-channel x 10-time slice, scaled linearly
+    in rows; the CG as iterations x one timed application of the full-size operator."""
+    from oracle import beams as obeams, gcr_cosmo as oc, gcr_ptsrc as op_
+    nant = len(ant_pos)
+    nf_s, nt_s = 1, min(10, times.size)
+    f_s, t_s = freqs[:nf_s], times[:nt_s]
+    beams = [obeams.GaussianBeam(14.0) for _ in range(nant)]
+    t0 = time.perf_counter()
+    proj = op_.calc_proj_operator(g_ra, g_dec, np.ones((g_ra.size, nf_s)), ant_pos, antpairs, f_s, t_s,
+                                  beams, -30.7215 * np.pi / 180.0)
+    t_resp = time.perf_counter() - t0
+    nbl = len(antpairs)
+    rng = np.random.RandomState(0)
+    gains = g0[:, None, None] * np.ones((nant, nf_s, nt_s))
+    data = rng.randn(nbl, nf_s, nt_s) + 1j * rng.randn(nbl, nf_s, nt_s)
+    inv_noise = np.full((nbl, nf_s, nt_s), 1.0 / sigma ** 2)
+    t0 = time.perf_counter()
+    oc.precompute(np.arange(nant), antpairs, freqs, f_s, proj, data, inv_noise, gains, pspec3d)
+    t_pre = time.perf_counter() - t0
+    rows = nbl * nf_s * nt_s
+    xv = rng.randn(*pspec3d.shape)
+    t0 = time.perf_counter()
+    for _ in range(3):
+        oc.apply_lhs_operator(xv, op_full, pspec3d)
+    t_mv = (time.perf_counter() - t0) / 3
+    total = t_pre * full_rows / rows + iters * t_mv
+    return {"value": 1.0 / total, "unit": "samples/s", "cores": len(os.sched_getaffinity(0)),
+            "kind": "port",
+            "sample": (f"oracle precompute on a {nf_s}x{nt_s} (freq x time) slice = {rows} of "
+                       f"{full_rows} rows ({t_pre:.2f}s, scaled linearly in rows) + {iters} CG "
+                       f"iterations x one full-size operator application ({t_mv * 1e3:.1f} ms); "
+                       f"response build {t_resp:.2f}s not counted")}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + sorted(SH_CONFIGS) + sorted(GAIN_CONFIGS))
+    ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + sorted(SH_CONFIGS) + sorted(GAIN_CONFIGS)
+                    + sorted(COSMO_CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cg-tol", type=float, default=1e-8)
     ap.add_argument("--gram", default="auto", choices=["auto", "general"],
@@ -485,6 +656,8 @@ def main():
         return main_sh(args, comm, rank, world, dev)
     if args.config in GAIN_CONFIGS:
         return main_gain(args, comm, rank, world, dev)
+    if args.config in COSMO_CONFIGS:
+        return main_cosmo(args, comm, rank, world, dev)
 
     hex_spec, ns, nf, nt = CONFIGS[args.config]
     big = args.config in ("c5s", "c5")

@@ -1,10 +1,13 @@
 #!/usr/bin/env python
 """
 Gibbs driver on MI355X: the counterpart of the reference's ``example.py`` for the heads that sit
-on the GCR hot path -- point-source amplitudes (--ptsrc), linearised gains (--gains) and
-spherical-harmonic modes (--sh) -- with the reference's flag names (hydra/config.py) and output
-files (ptsrc_amps0.npy, sim_*_w%04d.npy, src_amp_%05d.npy, delta_g_amps_%05d.npy,
-sh_amp_%05d.npy; example.py:191-192,405-408,740,953,1061).
+on the GCR hot path -- point-source amplitudes (--ptsrc), linearised gains (--gains),
+spherical-harmonic modes (--sh) and the cosmological field (--cosmo) -- with the reference's flag
+names (hydra/config.py) and output files (ptsrc_amps0.npy, sim_*_w%04d.npy, src_amp_%05d.npy,
+delta_g_amps_%05d.npy, sh_amp_%05d.npy; example.py:191-192,405-408,740,953,1061).  The
+reference's cosmo step plots its first solution and exits (example.py:829-841); here every
+sample is saved as cosmo_field_%05d.npy and, as there (:850-851), does not feed back into the
+data model.
 
     python example.py --ptsrc --gains --Niters 10
     python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 example.py --ptsrc
@@ -12,8 +15,9 @@ sh_amp_%05d.npy; example.py:191-192,405-408,740,953,1061).
 One process per GPU; the frequency channels are split over ranks (the reference splits a
 freq x time grid over MPI ranks, example.py:161-174) and ``hydra_amd._dist.Comm`` stands where
 ``MPI.COMM_WORLD`` stood.  All arrays of the loop stay in HBM; the operator of the source head
-is kept in factored form.  Heads outside the hot path (--cosmo, --regions, --beam, --vis) are
-not provided.
+is kept in factored form.  --regions needs a pygdsm sky model (not shipped; the region operator
+itself is hydra_amd.region_sampler.calc_proj_operator); --beam and --vis are outside the hot
+path.
 """
 import argparse
 import os
@@ -33,6 +37,7 @@ def get_config(argv=None):
     p.add_argument("--ptsrc", action="store_true", dest="sample_ptsrc")
     p.add_argument("--gains", action="store_true", dest="sample_gains")
     p.add_argument("--sh", action="store_true", dest="sample_sh")
+    p.add_argument("--cosmo", action="store_true", dest="sample_cosmo_field")
     p.add_argument("--timing", action="store_true", dest="save_timing_info")
     p.add_argument("--latitude", type=float, default=-30.7215, dest="latitude")
     p.add_argument("--hex-array", type=int, nargs=2, default=(3, 4), dest="hex_array")
@@ -55,6 +60,12 @@ def get_config(argv=None):
     p.add_argument("--gain-only-positive-modes", type=bool, default=True,
                    dest="gain_only_positive_modes")
     p.add_argument("--sim-gain-amp-std", type=float, default=0.05, dest="sim_gain_amp_std")
+    p.add_argument("--cosmo-ra-bounds", type=float, nargs=2, default=(0, 60),
+                   dest="cosmo_field_ra_bounds")
+    p.add_argument("--cosmo-dec-bounds", type=float, nargs=2, default=(-40.0, -20.0),
+                   dest="cosmo_field_dec_bounds")
+    p.add_argument("--cosmo-ra-ngrid", type=int, default=10, dest="cosmo_field_ra_ngrid")
+    p.add_argument("--cosmo-dec-ngrid", type=int, default=10, dest="cosmo_field_dec_ngrid")
     p.add_argument("--sh-lmax", type=int, default=8, dest="sh_lmax")
     p.add_argument("--sh-nside", type=int, default=16, dest="sh_nside")
     p.add_argument("--sh-prior-std", type=float, default=0.1, dest="sh_prior_std")
@@ -142,6 +153,22 @@ def main(argv=None):
                   _dev.stream_ptr())
         model0_chunk = model0_chunk + sh_model0
         log("SH response operator took %6.3f sec" % (time.time() - t0), "c")
+
+    cosmo_proj = None
+    if args.sample_cosmo_field:                          # example.py:539-594
+        t0 = time.time()
+        cosmo_grid_ra, cosmo_grid_dec = hydra.cosmo_sampler.make_cosmo_field_grid(args)
+        cosmo_proj = hydra.ptsrc_sampler.calc_proj_operator(
+            ra=cosmo_grid_ra, dec=cosmo_grid_dec,
+            fluxes=np.ones((cosmo_grid_ra.size, freq_chunk.size)), ant_pos=ant_pos,
+            antpairs=antpairs, freqs=freq_chunk, times=time_chunk, beams=beams, latitude=lat,
+            materialize=False)
+        cosmo_x, cosmo_y = np.unique(cosmo_grid_ra), np.unique(cosmo_grid_dec)
+        cosmo_pspec_kbins = np.linspace(0.0, 10, 25)
+        cosmo_pspec_current = 0.1 * cosmo_pspec_kbins + np.ones(cosmo_pspec_kbins.size)
+        cosmo_background_params = {"h": 0.69, "omega_m": 0.31}
+        cosmo_soln_shape = (freqs.size, cosmo_x.size, cosmo_y.size)
+        log("Cosmo field projection operator (factored) took %6.3f sec" % (time.time() - t0), "c")
 
     # ---- gains and simulated data (example.py:322-408)
     Lfreq, Ltime = freqs[-1] - freqs[0], times[-1] - times[0]
@@ -235,6 +262,31 @@ def main(argv=None):
                 np.save(os.path.join(out, "delta_g_amps_%05d" % n), xg.cpu().numpy())
             current_delta_gain = torch.tensordot(xg, Fbasis, dims=([1], [0]))
             timing(n, "(A) Gain sampler", time.time() - t0)
+
+        if args.sample_cosmo_field:                      # (BBBB) example.py:751-851
+            t0 = time.time()
+            ggv = hydra.apply_gains(model_ptsrc + model_sh, gains_chunk, ants, antpairs,
+                                    inline=False)
+            pspec3d = hydra.cosmo_sampler.calculate_pspec_on_grid(
+                kbins=cosmo_pspec_kbins, pspec=cosmo_pspec_current, x=cosmo_x, y=cosmo_y,
+                freqs=freqs, **cosmo_background_params)
+            cosmo_op, cosmo_rhs = hydra.cosmo_sampler.precompute_mpi(
+                comm, freqs=freqs, ants=ants, antpairs=antpairs, freq_chunk=freq_chunk,
+                time_chunk=time_chunk, proj_chunk=cosmo_proj, data_chunk=data_chunk - ggv,
+                inv_noise_var_chunk=inv_noise_var_chunk,
+                gain_chunk=gains_chunk * (1.0 + current_delta_gain), pspec3d=pspec3d,
+                realisation=True)
+            if myid == 0:
+                p3d = tdev(pspec3d, torch.float64)
+                cosmo_soln = hydra.linear_solver.cg(
+                    Amat=None, bvec=cosmo_rhs.flatten(),
+                    linear_op=lambda v: hydra.cosmo_sampler.apply_lhs_operator(
+                        v.reshape(cosmo_soln_shape), cosmo_op, p3d).flatten())
+                np.save(os.path.join(out, "cosmo_field_%05d" % n),
+                        cosmo_soln.reshape(cosmo_soln_shape).cpu().numpy())
+            if comm is not None:
+                comm.barrier()
+            timing(n, "(BBBB) Cosmo field sampler", time.time() - t0)
 
         if args.sample_ptsrc:                            # (B) example.py:856-984
             t0 = time.time()

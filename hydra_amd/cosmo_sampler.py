@@ -26,7 +26,7 @@ from scipy.integrate import cumulative_trapezoid
 from scipy.interpolate import interp1d
 
 from . import _dev, _tables
-from .ptsrc_sampler import FactoredProj
+from .ptsrc_sampler import FactoredProj, _timed_gram
 
 C = 299792.458               # speed of light, km/s        (cosmo_sampler.py:11)
 FREQ_21CM = 1420.405751768   # MHz                         (cosmo_sampler.py:12)
@@ -176,7 +176,8 @@ def precompute_mpi(comm, ants, antpairs, freqs, freq_chunk, time_chunk, proj_chu
         z_j = z[:, j:j + 1, :].contiguous()
         if factored:
             sub = proj_chunk.channel(j)
-            G_j = sub.gram(g_j, w_j)
+            G_j = _timed_gram(lambda: sub.gram(g_j, w_j))
+            proj_chunk.last_gram_kernel = sub.last_gram_kernel
             b_j = sub.adjoint(z_j)
         else:
             R_j = R_all[:, j].reshape(nbl * nt, npix).contiguous()

@@ -709,6 +709,10 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
 }
 
 // Sum the slabs of the 96 x 128 tiles in split order, scale, mirror, apply the epilogue.
+// grid (ntiles, K3_FIN_CHUNKS): a workgroup owns 1024 entries of one tile, 4 per thread, and
+// keeps 16 slab loads in flight per thread (the sum over splits is the only long loop here).
+constexpr int K3_FIN_CHUNKS = K3_TILE / 1024;
+static_assert(K3_TILE % 1024 == 0, "finish kernel: 4 entries per thread, 256 threads");
 __global__ void __launch_bounds__(256)
 gram_finish_k3_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, int ns,
                       const double* __restrict__ prior_std, const double* __restrict__ add_diag,
@@ -716,21 +720,39 @@ gram_finish_k3_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, 
   int tile = blockIdx.x;
   int ti, tj;
   k3_tile_of(tile, (ns + K3_TC - 1) / K3_TC, &ti, &tj);
-  for (int e = threadIdx.x; e < K3_TILE; e += blockDim.x) {
+  const size_t stride = (size_t)ntiles * K3_TILE;
+  const double* base = slabs + (size_t)tile * K3_TILE + blockIdx.y * 1024 + threadIdx.x;
+  double sum[4] = {0.0, 0.0, 0.0, 0.0};
+  int s = 0;
+  for (; s + 4 <= nsplit; s += 4) {
+    double v[4][4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) v[u][q] = base[(size_t)(s + u) * stride + q * 256];
+#pragma unroll
+    for (int u = 0; u < 4; ++u)      // split order, as a serial sum would do
+#pragma unroll
+      for (int q = 0; q < 4; ++q) sum[q] += v[u][q];
+  }
+  for (; s < nsplit; ++s)
+#pragma unroll
+    for (int q = 0; q < 4; ++q) sum[q] += base[(size_t)s * stride + q * 256];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    int e = blockIdx.y * 1024 + q * 256 + threadIdx.x;
     int r = e / K3_TC, c = e % K3_TC;
     int gi = ti * K3_TR + r, gj = tj * K3_TC + c;
     if (gi >= ns || gj >= ns || gj > gi) continue;
-    double sum = 0.0;
-    for (int s = 0; s < nsplit; ++s) sum += slabs[((size_t)s * ntiles + tile) * K3_TILE + e];
-    sum *= scale;
+    double val = sum[q] * scale;
     if (prior_std) {
-      sum = prior_std[gi] * sum * prior_std[gj];
-      if (gi == gj) sum = 1.0 + sum;
+      val = prior_std[gi] * val * prior_std[gj];
+      if (gi == gj) val = 1.0 + val;
     } else if (add_diag && gi == gj) {
-      sum += add_diag[gi];
+      val += add_diag[gi];
     }
-    G[(size_t)gi * ns + gj] = sum;
-    if (gi != gj) G[(size_t)gj * ns + gi] = sum;
+    G[(size_t)gi * ns + gj] = val;
+    if (gi != gj) G[(size_t)gj * ns + gi] = val;
   }
 }
 
@@ -743,7 +765,8 @@ static void k3_plan(long long nft, int ns, int* ntiles, int* nsplit, long long* 
   }
   long long want = std::max<long long>(8, 4096 / *ntiles);
   want = (want + 7) / 8 * 8;
-  long long cap = std::max<long long>(8, nft / 8 * 8);
+  // at least ~8 (f,t) samples per workgroup: each one writes a whole slab of its tile at the end
+  long long cap = std::max<long long>(8, nft / 64 * 8);
   want = std::min<long long>(std::min<long long>(want, cap), 512);
   *per = (nft + want - 1) / want;
   *nsplit = (int)want;
@@ -963,7 +986,7 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   }
   profile_record(1, st);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform");
-  gram_finish_k3_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G, 0.5);
+  gram_finish_k3_kernel<<<dim3(ntiles, K3_FIN_CHUNKS), 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G, 0.5);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform(finish)");
   return HYDRA_OK;
 }

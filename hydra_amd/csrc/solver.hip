@@ -135,6 +135,95 @@ cg_step_kernel(int n, const double* __restrict__ Ap, double* __restrict__ x,
   }
 }
 
+// The same iteration for long vectors (the cosmological-field head solves for 10^4-10^5 unknowns
+// with a cheap operator): one workgroup streams x, r, p, Ap through a single CU at ~30 GB/s, so the
+// step is split over up to CGL_MAXB workgroups and three launches, the dot products passing through
+// per-workgroup partial sums in st[8..] (summed in index order by every workgroup: deterministic).
+constexpr int CGL_T = 256;
+constexpr int CGL_MAXB = 256;
+constexpr int CG_STATE_LEN = 8 + 3 * CGL_MAXB;
+constexpr int CGL_MIN_N = 8192;
+
+__device__ __forceinline__ double cgl_block_sum(double v, double* s_red) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_sum(v);
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  return (s_red[0] + s_red[1]) + (s_red[2] + s_red[3]);
+}
+__device__ __forceinline__ double cgl_block_max(double v, double* s_red) {
+  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  v = wave_max(v);
+  __syncthreads();
+  if (lane == 0) s_red[wave] = v;
+  __syncthreads();
+  return fmax(fmax(s_red[0], s_red[1]), fmax(s_red[2], s_red[3]));
+}
+// sum (or max) of the nblk per-workgroup partials, same order in every workgroup
+__device__ __forceinline__ double cgl_gather(const double* part, int nblk, bool is_max, double* s_red) {
+  double v = (threadIdx.x < nblk) ? part[threadIdx.x] : 0.0;   // nblk <= CGL_MAXB == CGL_T
+  return is_max ? cgl_block_max(v, s_red) : cgl_block_sum(v, s_red);
+}
+
+__global__ void __launch_bounds__(CGL_T)
+cgl_dot_kernel(int n, const double* __restrict__ Ap, const double* __restrict__ p,
+               double* __restrict__ st) {
+  __shared__ double s_red[4];
+  if (st[1] != 0.0) return;
+  double pap = 0.0;
+  for (int i = blockIdx.x * CGL_T + threadIdx.x; i < n; i += gridDim.x * CGL_T) pap += p[i] * Ap[i];
+  pap = cgl_block_sum(pap, s_red);
+  if (threadIdx.x == 0) st[8 + blockIdx.x] = pap;
+}
+
+__global__ void __launch_bounds__(CGL_T)
+cgl_update_kernel(int n, const double* __restrict__ Ap, const double* __restrict__ p,
+                  double* __restrict__ x, double* __restrict__ r, double* __restrict__ st) {
+  __shared__ double s_red[4];
+  const double done = st[1];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    st[4] = st[0];   // rr and the done flag as they were when this iteration started: the last
+    st[5] = done;    // launch of the step reads these while workgroup 0 rewrites st[0..3]
+  }
+  if (done != 0.0) return;
+  double pap = cgl_gather(st + 8, gridDim.x, false, s_red);
+  double alpha = st[0] / pap;
+  double rr_new = 0.0, mx = 0.0;
+  for (int i = blockIdx.x * CGL_T + threadIdx.x; i < n; i += gridDim.x * CGL_T) {
+    x[i] = x[i] + alpha * p[i];
+    double ri = r[i] - alpha * Ap[i];
+    r[i] = ri;
+    rr_new += ri * ri;
+    mx = fmax(mx, fabs(ri));
+  }
+  rr_new = cgl_block_sum(rr_new, s_red);
+  mx = cgl_block_max(mx, s_red);
+  if (threadIdx.x == 0) {
+    st[8 + CGL_MAXB + blockIdx.x] = rr_new;
+    st[8 + 2 * CGL_MAXB + blockIdx.x] = mx;
+  }
+}
+
+__global__ void __launch_bounds__(CGL_T)
+cgl_dir_kernel(int n, const double* __restrict__ r, double* __restrict__ p,
+               double* __restrict__ st, double tol, int use_norm) {
+  __shared__ double s_red[4];
+  if (st[5] != 0.0) return;
+  double rr_new = cgl_gather(st + 8 + CGL_MAXB, gridDim.x, false, s_red);
+  double mx = cgl_gather(st + 8 + 2 * CGL_MAXB, gridDim.x, true, s_red);
+  double beta = rr_new / st[4];
+  for (int i = blockIdx.x * CGL_T + threadIdx.x; i < n; i += gridDim.x * CGL_T)
+    p[i] = r[i] + beta * p[i];
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    double res = use_norm ? sqrt(rr_new) : mx;
+    st[0] = rr_new;
+    st[1] = (res < tol) ? 1.0 : 0.0;
+    st[2] = st[2] + 1.0;
+    st[3] = res;
+  }
+}
+
 // ---------------------------------------------------------------- blocked Cholesky
 
 constexpr int NB = 32;
@@ -454,15 +543,25 @@ int hydra_cg_init(int n, const double* b, const double* Ax, double* r, double* p
 int hydra_cg_step(int n, const double* Ap, double* x, double* r, double* p, double* st,
                   double abs_tol, int use_norm_tol, void* stream) {
   HYDRA_CHECK_ARG(n > 0 && Ap && x && r && p && st, "hydra_cg_step: bad arguments");
-  cg_step_kernel<<<1, CG_THREADS, 0, as_stream(stream)>>>(n, Ap, x, r, p, st, abs_tol,
-                                                          use_norm_tol);
+  if (n >= CGL_MIN_N) {
+    int nblk = std::min(CGL_MAXB, (n + 4 * CGL_T - 1) / (4 * CGL_T));
+    hipStream_t s = as_stream(stream);
+    cgl_dot_kernel<<<nblk, CGL_T, 0, s>>>(n, Ap, p, st);
+    cgl_update_kernel<<<nblk, CGL_T, 0, s>>>(n, Ap, p, x, r, st);
+    cgl_dir_kernel<<<nblk, CGL_T, 0, s>>>(n, r, p, st, abs_tol, use_norm_tol);
+  } else {
+    cg_step_kernel<<<1, CG_THREADS, 0, as_stream(stream)>>>(n, Ap, x, r, p, st, abs_tol,
+                                                            use_norm_tol);
+  }
   HYDRA_CHECK_LAUNCH("hydra_cg_step");
   return HYDRA_OK;
 }
 
+int hydra_cg_state_len(void) { return CG_STATE_LEN; }
+
 size_t hydra_cg_workspace_bytes(int n) {
   if (n <= 0) return 0;
-  return ((size_t)3 * n + 8) * sizeof(double);
+  return ((size_t)3 * n + CG_STATE_LEN) * sizeof(double);
 }
 
 int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int maxiters,

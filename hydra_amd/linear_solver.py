@@ -46,7 +46,7 @@ def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
     x = _dev.f64(x0).clone() if x0 is not None else torch.zeros_like(b)
     r = torch.empty_like(b)
     p = torch.empty_like(b)
-    st = _dev.zeros((8,), torch.float64)
+    st = _dev.zeros((_dev._lib.query("hydra_cg_state_len"),), torch.float64)
     sp = _dev.stream_ptr()
 
     def op(v):

@@ -230,8 +230,9 @@ int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* 
 
 /* Conjugate gradients exactly as linear_solver.cg (linear_solver.py:378-509):
  * convergence tested BEFORE each iteration, element-wise |r_i| < tol or ||r||_2 < tol.
- * State (device): x, r, p (N) f64 and `st` = 8 doubles:
- *   st[0]=rr  st[1]=done(0/1)  st[2]=iterations done  st[3]=max|r| or ||r||  st[4..7] scratch.
+ * State (device): x, r, p (N) f64 and `st` = hydra_cg_state_len() doubles (776):
+ *   st[0]=rr  st[1]=done(0/1)  st[2]=iterations done  st[3]=max|r| or ||r||  st[4..] scratch
+ *   (per-workgroup partial sums of the multi-workgroup step used for long vectors).
  * hydra_cg_init: given x and r0 = b - A x (caller computes A x): p=r, rr=r.r, test.
  * hydra_cg_step: given Ap = A p, one fused update (both dot products, x/r/p updates, test).
  *   Once done==1 a step is a no-op, so the host may enqueue steps ahead of the test.     */
@@ -239,6 +240,7 @@ int hydra_cg_init(int n, const double* b, const double* Ax, double* r, double* p
                   double abs_tol, int use_norm_tol, void* stream);
 int hydra_cg_step(int n, const double* Ap, double* x, double* r, double* p, double* st,
                   double abs_tol, int use_norm_tol, void* stream);
+int hydra_cg_state_len(void);
 
 /* Whole dense solve on the device: x (in: x0, out: solution), A (N,N), b (N).
  * workspace >= hydra_cg_workspace_bytes(n).  Runs at most maxiters iterations, enqueuing

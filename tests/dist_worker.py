@@ -3,7 +3,7 @@ Worker run under torch.distributed.run by tests/test_dist.py (gloo backend, 127.
 
     python -m torch.distributed.run --nproc-per-node N tests/dist_worker.py <case>
 
-Cases "comm" and "blocks" need no GPU; "ptsrc" and "cgmpi" run every rank on GPU 0 of the box
+Cases "comm" and "blocks" need no GPU; "ptsrc", "blshard", "cosmo" and "cgmpi" run every rank on GPU 0 of the box
 (collectives staged through the host by hydra_amd._dist.Comm) and compare with a single-process
 run of the same path.
 """
@@ -210,6 +210,28 @@ def case_cgmpi(comm):
     comm.barrier()
 
 
+def case_cosmo(comm):
+    """Frequency-sharded cosmo_sampler.precompute_mpi (each rank holds a slice of the field's
+    channels; blocks of the other channels stay zero until comm.Reduce, cosmo_sampler.py:295-299,
+    339-340) == the single-process system built from golden inputs of the reference."""
+    import hydra_amd as hy
+    rank, size = comm.Get_rank(), comm.Get_size()
+    g = np.load(os.path.join(ROOT, "tests", "golden", "cosmo.npz"))
+    ap = [tuple(int(x) for x in pr) for pr in g["antpairs"]]
+    fidx = np.array_split(np.arange(g["freqs"].size), size)[rank]
+    op, rhs = hy.cosmo_sampler.precompute_mpi(
+        comm, g["ants"], ap, g["freqs"], g["freqs"][fidx], g["times"], g["proj"][:, fidx],
+        g["data"][:, fidx], g["inv_noise"][:, fidx], g["gains"][:, fidx], g["pspec3d"],
+        omega_n=g["omega_n"][:, fidx], omega_s=g["omega_s"])
+    if rank == 0:
+        ea = np.max(np.abs(op - g["op"])) / np.max(np.abs(g["op"]))
+        eb = np.max(np.abs(rhs - g["rhs"])) / np.max(np.abs(g["rhs"]))
+        assert ea < 1e-10 and eb < 1e-10, (ea, eb)
+    else:
+        assert op.shape == (1, 1, 1) and rhs.shape == (1, 1)     # dummies off the root
+    comm.barrier()
+
+
 if __name__ == "__main__":
     case = sys.argv[1]
     logdir = sys.argv[2] if len(sys.argv) > 2 else None
@@ -217,7 +239,7 @@ if __name__ == "__main__":
     assert comm is not None, "run under torch.distributed.run with WORLD_SIZE > 1"
     try:
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
-         "blshard": case_blshard, "cgmpi": case_cgmpi}[case](comm)
+         "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo}[case](comm)
     except BaseException:
         import traceback
         if logdir:

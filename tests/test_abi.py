@@ -59,7 +59,8 @@ def test_argument_validation_returns_error_codes():
     assert lib.hydra_gram_workspace_bytes(14400, 100) > 0
     # workspace query is consistent: more rows never needs less than 8 splits of one tile
     assert lib.hydra_gram_workspace_bytes(14400, 100) % (128 * 128 * 8) == 0
-    assert lib.hydra_cg_workspace_bytes(100) == (3 * 100 + 8) * 8
+    assert lib.hydra_cg_state_len() == 776
+    assert lib.hydra_cg_workspace_bytes(100) == (3 * 100 + 776) * 8
 
 
 def test_fused_gram_rejects_malformed_tables():

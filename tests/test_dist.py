@@ -60,5 +60,10 @@ def test_baseline_sharded_ptsrc_system_world3():
 
 
 @pytest.mark.gpu
+def test_freq_sharded_cosmo_system_world3():
+    _run("cosmo", 3)
+
+
+@pytest.mark.gpu
 def test_cg_mpi_world4():
     _run("cgmpi", 4)

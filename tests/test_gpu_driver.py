@@ -52,3 +52,15 @@ def test_sh_head_samples_the_simulated_modes(tmp_path):
     # a posterior sample: within the prior range, and correlated with the simulated sky
     assert np.max(np.abs(a)) < 1.0
     assert np.corrcoef(a, truth)[0, 1] > 0.3
+
+
+def test_cosmo_head_writes_field_samples(tmp_path):
+    out = _run(tmp_path, ["--cosmo", "--ptsrc", "--cosmo-ra-bounds", "5", "40", "--cosmo-dec-bounds",
+                          "-40", "-20", "--cosmo-ra-ngrid", "6", "--cosmo-dec-ngrid", "5"])
+    for n in range(4):
+        f = np.load(os.path.join(out, "cosmo_field_%05d.npy" % n))
+        assert f.shape == (8, 6, 5) and np.all(np.isfinite(f))
+        x = np.load(os.path.join(out, "src_amp_%05d.npy" % n))
+        assert x.shape == (20,) and np.all(np.isfinite(x))
+    # the simulated sky holds no cosmological field: samples scatter about zero at the prior level
+    assert np.abs(f).max() < 20.0 and abs(f.mean()) < 1.0

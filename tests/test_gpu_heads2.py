@@ -268,3 +268,40 @@ def test_region_operator_edge_cases_and_joint_system(hy):
     assert relerr(A, A_ref) < OP_TOL and relerr(b, b_ref) < OP_TOL
     x = hy.linear_solver.solve_dense(A, b)
     assert relerr(np.asarray(x), gcr_ptsrc.dense_solve(A_ref, b_ref)) < SAMPLE_TOL
+
+
+# ------------------------------------------------------------------ CG on long vectors
+
+@pytest.mark.parametrize("use_norm_tol", [False, True])
+def test_cg_long_vector_step_matches_oracle(hy, use_norm_tol):
+    """n >= 8192 takes the multi-workgroup CG step (csrc/solver.hip): same iterates as the
+    oracle's restatement of linear_solver.cg, for a callable operator and for a dense matrix."""
+    import torch
+    from oracle import cg as ocg
+    rng = np.random.RandomState(17)
+    n, k = 20011, 6
+    d = rng.uniform(1.0, 3.0, n)
+    U = rng.randn(n, k) / np.sqrt(n)
+    b = rng.randn(n)
+    x0 = rng.randn(n) * 0.1
+    tol = 1e-9 if not use_norm_tol else 1e-7
+
+    def op_np(v):
+        return d * v + U @ (U.T @ v)
+    x_ref = ocg.cg(None, b, maxiters=500, abs_tol=tol, use_norm_tol=use_norm_tol, x0=x0.copy(),
+                   linear_op=op_np)
+    dd, Ud = torch.as_tensor(d).cuda(), torch.as_tensor(U).cuda()
+    x, iters = hy.linear_solver.cg(None, torch.as_tensor(b).cuda(), maxiters=500, abs_tol=tol,
+                                   use_norm_tol=use_norm_tol, x0=torch.as_tensor(x0).cuda(),
+                                   linear_op=lambda v: dd * v + Ud @ (Ud.T @ v), return_iters=True)
+    assert 2 < iters < 500
+    assert relerr(x.cpu().numpy(), x_ref) < SAMPLE_TOL
+    # dense matrix path (hydra_cg_solve_dense) just above the switch-over length
+    n2 = 8200
+    B = rng.randn(n2, 40) / np.sqrt(n2)
+    A = np.diag(rng.uniform(1.0, 2.0, n2)) + B @ B.T
+    b2 = rng.randn(n2)
+    x2_ref = ocg.cg(A, b2, maxiters=300, abs_tol=tol, use_norm_tol=use_norm_tol)
+    x2 = hy.linear_solver.cg(A, b2, maxiters=300, abs_tol=tol, use_norm_tol=use_norm_tol)
+    assert relerr(x2, x2_ref) < SAMPLE_TOL
+    assert np.abs(A @ x2 - b2).max() < 10 * tol
