@@ -105,8 +105,17 @@ def apply_lhs_operator(x, lhs_Ninv_operator, pspec3d):
     G = _dev.f64(lhs_Ninv_operator)
     assert tuple(G.shape) == (nf, npix, npix)
     y = _apply_S_dev(xd, _dev.f64(pspec3d), -1.0).reshape(nf, npix)
-    _dev.call("hydra_gemv_batched", _dev.ptr(G), npix, nf, _dev.ptr(xd), _dev.ptr(y), 1,
-              _dev.stream_ptr())
+    # the blocks are symmetric bit for bit (the Gram kernels mirror the lower triangle), which
+    # lets the product read half of each; any other stack of matrices gets the plain product
+    if getattr(lhs_Ninv_operator, "hydra_symmetric", None) is None and _dev.is_torch(lhs_Ninv_operator):
+        lhs_Ninv_operator.hydra_symmetric = bool(torch.equal(G, G.transpose(1, 2)))
+    if getattr(lhs_Ninv_operator, "hydra_symmetric", False):
+        ws = _dev.workspace(_dev._lib.query("hydra_symv_workspace_bytes", npix, nf))
+        _dev.call("hydra_symv_batched", _dev.ptr(G), npix, nf, _dev.ptr(xd), _dev.ptr(y), 1,
+                  _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+    else:
+        _dev.call("hydra_gemv_batched", _dev.ptr(G), npix, nf, _dev.ptr(xd), _dev.ptr(y), 1,
+                  _dev.stream_ptr())
     return _dev.like(x, y)
 
 

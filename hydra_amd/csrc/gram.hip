@@ -538,13 +538,17 @@ uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
 __global__ void __launch_bounds__(256)
 noise_uniform_kernel(const double* __restrict__ w, int nbl, int nft, double* __restrict__ wft,
                      int32_t* __restrict__ flag) {
-  int ft = blockIdx.x * blockDim.x + threadIdx.x;
-  if (ft >= nft) return;
-  double w0 = w[ft];
+  // one entry of w per thread and trip: compare with baseline 0 of the same (f,t)
+  const size_t total = (size_t)nbl * nft;
   bool bad = false;
-  for (int b = 1; b < nbl; ++b) bad |= (w[(size_t)b * nft + ft] != w0);
-  wft[ft] = w0;
-  if (bad) atomicOr(flag, 1);
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    int ft = (int)(e % nft);
+    double w0 = w[ft], we = w[e];
+    if (e < (size_t)nft) wft[ft] = w0;
+    bad |= (we != w0);
+  }
+  if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
 // ---- 3-product form of the closed-form Gram ---------------------------------------------
@@ -939,8 +943,9 @@ int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, dou
   HYDRA_CHECK_ARG(inv_noise && w_ft && flag && nbl > 0 && nf > 0 && nt > 0,
                   "hydra_noise_uniformity: bad arguments");
   int nft = nf * nt;
-  noise_uniform_kernel<<<(nft + 255) / 256, 256, 0, as_stream(stream)>>>(inv_noise, nbl, nft, w_ft,
-                                                                         flag);
+  size_t total = (size_t)nbl * nft;
+  int grid = (int)std::min<size_t>((total + 255) / 256, 4096);
+  noise_uniform_kernel<<<grid, 256, 0, as_stream(stream)>>>(inv_noise, nbl, nft, w_ft, flag);
   HYDRA_CHECK_LAUNCH("hydra_noise_uniformity");
   return HYDRA_OK;
 }

@@ -26,7 +26,10 @@ gemv_kernel(const double* __restrict__ A, int n, const double* __restrict__ x,
 }
 
 // y[q] (+)= A[q] x[q] for a stack of nb independent (n,n) matrices (blockIdx.y = q): the
-// per-frequency likelihood term of the cosmological-field operator (cosmo_sampler.py:219-221)
+// per-frequency likelihood term of the cosmological-field operator (cosmo_sampler.py:219-221).
+// HBM-bound (8 n^2 bytes per matrix): a wave takes two rows at a time, 16-byte loads when the
+// rows are 16-byte aligned (n even), eight loads in flight per lane.
+template <bool VEC2>
 __global__ void __launch_bounds__(256)
 gemv_batched_kernel(const double* __restrict__ A, int n, const double* __restrict__ x,
                     double* __restrict__ y, int accumulate) {
@@ -34,18 +37,151 @@ gemv_batched_kernel(const double* __restrict__ A, int n, const double* __restric
   const double* Aq = A + (size_t)blockIdx.y * n * n;
   const double* xq = x + (size_t)blockIdx.y * n;
   double* yq = y + (size_t)blockIdx.y * n;
-  for (int r = blockIdx.x * 4 + wave; r < n; r += gridDim.x * 4) {
-    const double* ap = Aq + (size_t)r * n;
+  for (int r = 2 * (blockIdx.x * 4 + wave); r < n; r += 2 * gridDim.x * 4) {
+    const bool two = r + 1 < n;
+    const double* a0 = Aq + (size_t)r * n;
+    const double* a1 = Aq + (size_t)(two ? r + 1 : r) * n;
     double s0 = 0.0, s1 = 0.0;
-    int c = lane;
-    for (; c + 64 < n; c += 128) {
-      s0 += ap[c] * xq[c];
-      s1 += ap[c + 64] * xq[c + 64];
+    if (VEC2) {
+      const f64x2* v0 = reinterpret_cast<const f64x2*>(a0);
+      const f64x2* v1 = reinterpret_cast<const f64x2*>(a1);
+      const f64x2* xv = reinterpret_cast<const f64x2*>(xq);
+      const int nh = n / 2;
+      int c = lane;
+      for (; c + 192 < nh; c += 256) {
+        f64x2 p[4], q[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          p[u] = v0[c + 64 * u];
+          q[u] = v1[c + 64 * u];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          f64x2 xx = xv[c + 64 * u];
+          s0 += p[u].x * xx.x + p[u].y * xx.y;
+          s1 += q[u].x * xx.x + q[u].y * xx.y;
+        }
+      }
+      for (; c < nh; c += 64) {
+        f64x2 xx = xv[c], p = v0[c], q = v1[c];
+        s0 += p.x * xx.x + p.y * xx.y;
+        s1 += q.x * xx.x + q.y * xx.y;
+      }
+    } else {
+      for (int c = lane; c < n; c += 64) {
+        double xx = xq[c];
+        s0 += a0[c] * xx;
+        s1 += a1[c] * xx;
+      }
     }
-    if (c < n) s0 += ap[c] * xq[c];
-    double s = wave_sum(s0 + s1);
-    if (lane == 0) yq[r] = accumulate ? yq[r] + s : s;
+    s0 = wave_sum(s0);
+    s1 = wave_sum(s1);
+    if (lane == 0) {
+      yq[r] = accumulate ? yq[r] + s0 : s0;
+      if (two) yq[r + 1] = accumulate ? yq[r + 1] + s1 : s1;
+    }
   }
+}
+
+// y = A x for SYMMETRIC A stored in full, reading only the blocks on and below the diagonal
+// (4 n^2 instead of 8 n^2 bytes): the workgroup of block (bi, bj), bi >= bj, stages the 64 x 64
+// block B in LDS and forms both B x_j (rows of block bi) and, off the diagonal, B^T x_i (rows of
+// block bj).  Every (block column k, row) pair receives exactly one such piece, stored in
+// part[k][row]; a second launch sums the pieces in k order -- no atomics, reproducible sums.
+constexpr int SV_T = 64;
+constexpr int SV_LD = SV_T + 2;   // LDS row stride (doubles): even, so 16-byte stores stay aligned
+
+template <bool VEC2>
+__global__ void __launch_bounds__(256)
+symv_blocks_kernel(const double* __restrict__ A, int n, int nbk, const double* __restrict__ x,
+                   double* __restrict__ part) {
+  __shared__ __align__(16) double sB[SV_T * SV_LD];
+  __shared__ double sx[2][SV_T];        // x_j, x_i
+  __shared__ double so[2][2][SV_T];     // [product][half][row or column]
+  // linear block index -> (bi, bj), bj <= bi
+  int t = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * t + 1.0) - 1.0) * 0.5);
+  while ((bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  while (bi * (bi + 1) / 2 > t) --bi;
+  int bj = t - bi * (bi + 1) / 2;
+  const int q = blockIdx.y;
+  const double* Aq = A + (size_t)q * n * n;
+  const double* xq = x + (size_t)q * n;
+  double* pq = part + (size_t)q * nbk * n;
+  const int tid = threadIdx.x;
+  const int r0 = bi * SV_T, c0 = bj * SV_T;
+  if (VEC2) {   // n even: 16-byte loads, 32 per row, 8 rows per trip
+    const int cp = tid % 32, rr = tid / 32;
+    f64x2 v[8];
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+      int r = r0 + rr + 8 * k, c = c0 + 2 * cp;
+      v[k] = (r < n && c < n) ? *reinterpret_cast<const f64x2*>(Aq + (size_t)r * n + c)
+                              : f64x2{0.0, 0.0};    // n even: c < n implies c + 1 < n
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k)
+      *reinterpret_cast<f64x2*>(&sB[(rr + 8 * k) * SV_LD + 2 * cp]) = v[k];
+  } else {
+    const int cc = tid % 64, rr = tid / 64;
+    double v[16];
+#pragma unroll
+    for (int k = 0; k < 16; ++k) {
+      int r = r0 + rr + 4 * k, c = c0 + cc;
+      v[k] = (r < n && c < n) ? Aq[(size_t)r * n + c] : 0.0;
+    }
+#pragma unroll
+    for (int k = 0; k < 16; ++k) sB[(rr + 4 * k) * SV_LD + cc] = v[k];
+  }
+  if (tid < SV_T) sx[0][tid] = (c0 + tid < n) ? xq[c0 + tid] : 0.0;
+  else if (tid < 2 * SV_T) sx[1][tid - SV_T] = (r0 + tid - SV_T < n) ? xq[r0 + tid - SV_T] : 0.0;
+  __syncthreads();
+  {
+    const int which = tid >> 7, half = (tid >> 6) & 1, l = tid & 63;
+    double s0 = 0.0, s1 = 0.0;
+    if (which == 0) {   // (B x_j)[l] over columns [32 half, 32 half + 32)
+      const double* row = sB + l * SV_LD + 32 * half;
+      const double* xv = sx[0] + 32 * half;
+#pragma unroll
+      for (int c = 0; c < 32; c += 2) {
+        s0 += row[c] * xv[c];
+        s1 += row[c + 1] * xv[c + 1];
+      }
+    } else {            // (B^T x_i)[l] over rows [32 half, 32 half + 32)
+      const double* col = sB + (32 * half) * SV_LD + l;
+      const double* xv = sx[1] + 32 * half;
+#pragma unroll
+      for (int r = 0; r < 32; r += 2) {
+        s0 += col[r * SV_LD] * xv[r];
+        s1 += col[(r + 1) * SV_LD] * xv[r + 1];
+      }
+    }
+    so[which][half][l] = s0 + s1;
+  }
+  __syncthreads();
+  if (tid < SV_T) {
+    if (r0 + tid < n) pq[(size_t)bj * n + r0 + tid] = so[0][0][tid] + so[0][1][tid];
+  } else if (tid < 2 * SV_T && bi != bj) {
+    int l = tid - SV_T;
+    if (c0 + l < n) pq[(size_t)bi * n + c0 + l] = so[1][0][l] + so[1][1][l];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+symv_reduce_kernel(const double* __restrict__ part, int n, int nbk, double* __restrict__ y,
+                   int accumulate) {
+  int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= n) return;
+  const double* pq = part + (size_t)blockIdx.y * nbk * n + i;
+  double s0 = 0.0, s1 = 0.0;
+  int k = 0;
+  for (; k + 1 < nbk; k += 2) {
+    s0 += pq[(size_t)k * n];
+    s1 += pq[(size_t)(k + 1) * n];
+  }
+  if (k < nbk) s0 += pq[(size_t)k * n];
+  double* yq = y + (size_t)blockIdx.y * n;
+  yq[i] = accumulate ? yq[i] + (s0 + s1) : s0 + s1;
 }
 
 // ---------------------------------------------------------------- CG
@@ -526,9 +662,42 @@ int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* 
                        void* stream) {
   HYDRA_CHECK_ARG(A && x && y && n > 0 && nb > 0 && nb <= 65535,
                   "hydra_gemv_batched: bad arguments (n=%d, nb=%d)", n, nb);
-  dim3 grid(std::min((n + 3) / 4, 1024), nb);
-  gemv_batched_kernel<<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y, accumulate);
+  dim3 grid(std::min((n + 7) / 8, 1024), nb);
+  bool vec2 = n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+              reinterpret_cast<uintptr_t>(x) % 16 == 0;
+  if (vec2)
+    gemv_batched_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y, accumulate);
+  else
+    gemv_batched_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y, accumulate);
   HYDRA_CHECK_LAUNCH("hydra_gemv_batched");
+  return HYDRA_OK;
+}
+
+size_t hydra_symv_workspace_bytes(int n, int nb) {
+  if (n <= 0 || nb <= 0) return 0;
+  size_t nbk = ((size_t)n + SV_T - 1) / SV_T;
+  return (size_t)nb * nbk * n * sizeof(double);
+}
+
+int hydra_symv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream) {
+  HYDRA_CHECK_ARG(A && x && y && n > 0 && nb > 0 && nb <= 65535,
+                  "hydra_symv_batched: bad arguments (n=%d, nb=%d)", n, nb);
+  size_t need = hydra_symv_workspace_bytes(n, nb);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_symv_batched: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int nbk = (n + SV_T - 1) / SV_T;
+  long long nblocks = (long long)nbk * (nbk + 1) / 2;
+  HYDRA_CHECK_ARG(nblocks <= 2147483647LL, "hydra_symv_batched: n=%d is too large", n);
+  double* part = static_cast<double*>(workspace);
+  hipStream_t s = as_stream(stream);
+  bool vec2 = n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0;
+  dim3 grid((unsigned)nblocks, nb);
+  if (vec2) symv_blocks_kernel<true><<<grid, 256, 0, s>>>(A, n, nbk, x, part);
+  else      symv_blocks_kernel<false><<<grid, 256, 0, s>>>(A, n, nbk, x, part);
+  symv_reduce_kernel<<<dim3((n + 255) / 256, nb), 256, 0, s>>>(part, n, nbk, y, accumulate);
+  HYDRA_CHECK_LAUNCH("hydra_symv_batched");
   return HYDRA_OK;
 }
 
@@ -561,12 +730,12 @@ int hydra_cg_state_len(void) { return CG_STATE_LEN; }
 
 size_t hydra_cg_workspace_bytes(int n) {
   if (n <= 0) return 0;
-  return ((size_t)3 * n + CG_STATE_LEN) * sizeof(double);
+  return ((size_t)3 * n + CG_STATE_LEN) * sizeof(double) + hydra_symv_workspace_bytes(n, 1);
 }
 
 int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int maxiters,
-                         double abs_tol, int use_norm_tol, int check_every, int* iters_host,
-                         void* workspace, size_t workspace_bytes, void* stream) {
+                         double abs_tol, int use_norm_tol, int symmetric, int check_every,
+                         int* iters_host, void* workspace, size_t workspace_bytes, void* stream) {
   HYDRA_CHECK_ARG(A && b && x && n > 0 && maxiters >= 0, "hydra_cg_solve_dense: bad arguments");
   size_t need = hydra_cg_workspace_bytes(n);
   if (!workspace || workspace_bytes < need)
@@ -577,8 +746,15 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
   double* p = r + n;
   double* ap = p + n;
   double* st = ap + n;
+  void* sv_ws = st + CG_STATE_LEN;
+  size_t sv_bytes = hydra_symv_workspace_bytes(n, 1);
   hipStream_t s = as_stream(stream);
-  int rc = hydra_gemv(A, n, x, ap, stream);
+  // A p: half the matrix is read when the caller vouches for exact symmetry
+  auto matvec = [&](const double* v, double* out) {
+    return symmetric ? hydra_symv_batched(A, n, 1, v, out, 0, sv_ws, sv_bytes, stream)
+                     : hydra_gemv(A, n, v, out, stream);
+  };
+  int rc = matvec(x, ap);
   if (rc) return rc;
   rc = hydra_cg_init(n, b, ap, r, p, st, abs_tol, use_norm_tol, stream);
   if (rc) return rc;
@@ -592,7 +768,7 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
     if (st_host[1] != 0.0 || it >= maxiters) break;
     int chunk = std::min(check_every, maxiters - it);
     for (int c = 0; c < chunk; ++c) {
-      rc = hydra_gemv(A, n, p, ap, stream);
+      rc = matvec(p, ap);
       if (rc) return rc;
       rc = hydra_cg_step(n, ap, x, r, p, st, abs_tol, use_norm_tol, stream);
       if (rc) return rc;

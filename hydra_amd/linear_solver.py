@@ -31,8 +31,12 @@ def _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0):
     ws = _dev.workspace(_dev._lib.query("hydra_cg_workspace_bytes", n))
     import ctypes
     iters = ctypes.c_int(0)
+    # the GCR operators are symmetric by construction; checked (one pass over A) so that an
+    # unsymmetric Amat still gets the reference's A @ p
+    symmetric = bool(torch.equal(A, A.T))
     _dev.call("hydra_cg_solve_dense", _dev.ptr(A), _dev.ptr(b), _dev.ptr(x), n, int(maxiters),
-              float(abs_tol), int(bool(use_norm_tol)), CHECK_EVERY, ctypes.byref(iters),
+              float(abs_tol), int(bool(use_norm_tol)), int(symmetric), CHECK_EVERY,
+              ctypes.byref(iters),
               _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
     return x, iters.value
 

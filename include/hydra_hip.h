@@ -228,6 +228,15 @@ int hydra_gemv(const double* A, int n, const double* x, double* y, void* stream)
 int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
                        void* stream);
 
+/* The same products for SYMMETRIC matrices (A[q] == A[q]^T exactly, stored in full): only the
+ * 64 x 64 blocks on and below the diagonal are read -- half the HBM traffic.  workspace >=
+ * hydra_symv_workspace_bytes(n, nb) holds the per-block-column pieces that a second launch sums
+ * in a fixed order (no atomics).  The GCR operators are symmetric by construction
+ * (ptsrc_sampler.py:62-94, cosmo_sampler.py:284).                                          */
+size_t hydra_symv_workspace_bytes(int n, int nb);
+int hydra_symv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
+                       void* workspace, size_t workspace_bytes, void* stream);
+
 /* Conjugate gradients exactly as linear_solver.cg (linear_solver.py:378-509):
  * convergence tested BEFORE each iteration, element-wise |r_i| < tol or ||r||_2 < tol.
  * State (device): x, r, p (N) f64 and `st` = hydra_cg_state_len() doubles (776):
@@ -245,11 +254,12 @@ int hydra_cg_state_len(void);
 /* Whole dense solve on the device: x (in: x0, out: solution), A (N,N), b (N).
  * workspace >= hydra_cg_workspace_bytes(n).  Runs at most maxiters iterations, enqueuing
  * `check_every` iterations between host reads of the done flag.  *iters_host receives the
- * iteration count.                                  linear_solver.py:378-509 with Amat given */
+ * iteration count.  symmetric != 0: the caller vouches that A == A^T exactly and the products
+ * A p read half the matrix (hydra_symv_batched).    linear_solver.py:378-509 with Amat given */
 size_t hydra_cg_workspace_bytes(int n);
 int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int maxiters,
-                         double abs_tol, int use_norm_tol, int check_every, int* iters_host,
-                         void* workspace, size_t workspace_bytes, void* stream);
+                         double abs_tol, int use_norm_tol, int symmetric, int check_every,
+                         int* iters_host, void* workspace, size_t workspace_bytes, void* stream);
 
 /* Dense fallback: solve A x = b for symmetric positive definite A by blocked Cholesky
  * (stands for scipy.linalg.solve(A, b, assume_a='her'), example.py:944).  A is overwritten

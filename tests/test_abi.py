@@ -60,7 +60,8 @@ def test_argument_validation_returns_error_codes():
     # workspace query is consistent: more rows never needs less than 8 splits of one tile
     assert lib.hydra_gram_workspace_bytes(14400, 100) % (128 * 128 * 8) == 0
     assert lib.hydra_cg_state_len() == 776
-    assert lib.hydra_cg_workspace_bytes(100) == (3 * 100 + 776) * 8
+    assert lib.hydra_symv_workspace_bytes(100, 3) == 3 * 2 * 100 * 8
+    assert lib.hydra_cg_workspace_bytes(100) == (3 * 100 + 776) * 8 + 2 * 100 * 8
 
 
 def test_fused_gram_rejects_malformed_tables():

@@ -305,3 +305,33 @@ def test_cg_long_vector_step_matches_oracle(hy, use_norm_tol):
     x2 = hy.linear_solver.cg(A, b2, maxiters=300, abs_tol=tol, use_norm_tol=use_norm_tol)
     assert relerr(x2, x2_ref) < SAMPLE_TOL
     assert np.abs(A @ x2 - b2).max() < 10 * tol
+
+
+@pytest.mark.parametrize("n,nb", [(64, 1), (1, 2), (130, 3), (257, 2), (1000, 1)])
+def test_symmetric_half_read_matvec_matches_numpy(hy, n, nb):
+    """hydra_symv_batched (reads the lower blocks only) == A @ x for symmetric A; plain and
+    accumulating; odd n takes the 8-byte-load variant."""
+    import torch
+    from hydra_amd import _dev
+    rng = np.random.RandomState(n + nb)
+    A = rng.randn(nb, n, n)
+    A = A + A.transpose(0, 2, 1)
+    x = rng.randn(nb, n)
+    y0 = rng.randn(nb, n)
+    ref = np.einsum("qij,qj->qi", A, x)
+    Ad, xd = _dev.f64(A), _dev.f64(x)
+    ws = _dev.workspace(_dev._lib.query("hydra_symv_workspace_bytes", n, nb))
+    for acc in (0, 1):
+        yd = _dev.f64(y0).clone()
+        _dev.call("hydra_symv_batched", _dev.ptr(Ad), n, nb, _dev.ptr(xd), _dev.ptr(yd), acc,
+                  _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+        want = ref + (y0 if acc else 0.0)
+        assert relerr(yd.cpu().numpy(), want) < 1e-13
+    # the upper triangle above the diagonal blocks is never read
+    if n > 64:
+        A2 = A.copy()
+        A2[:, :64, 64:] = np.nan
+        yd = torch.empty_like(xd)
+        _dev.call("hydra_symv_batched", _dev.ptr(_dev.f64(A2)), n, nb, _dev.ptr(xd), _dev.ptr(yd), 0,
+                  _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+        assert relerr(yd.cpu().numpy(), ref) < 1e-13

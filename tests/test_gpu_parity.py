@@ -336,7 +336,9 @@ def test_cg_matches_reference_golden(hy, orc):
     assert relerr(x2, g["x2"]) < 5 * SAMPLE_TOL
     assert np.linalg.norm(g["A2"] @ x2 - g["b2"]) / np.linalg.norm(g["b2"]) < SAMPLE_TOL
     _, it_ref = orc.cg.cg(g["A2"], g["b2"], return_iters=True)
-    assert abs(it2 - it_ref) <= 5          # same algorithm; dot products summed in another order
+    # same algorithm; this matrix needs > n iterations, i.e. the trajectory is set by rounding, and
+    # the products / dot products are summed in another order than numpy's
+    assert abs(it2 - it_ref) <= 0.03 * it_ref
     x2a = hy.linear_solver.cg(None, g["b2"], maxiters=1000, abs_tol=1e-8,
                               linear_op=lambda v: g["A2"] @ v)
     assert np.allclose(g["xtrue"], x2a) and np.allclose(x2, x2a)
