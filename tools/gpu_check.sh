@@ -21,11 +21,16 @@ cd /tmp
 timeout -k 10 600 rocprofv3 --kernel-trace --stats -d "$ROOT/$OUT/prof_$CFG" -o "$CFG" -- \
     python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --no-cpu --steps 2 --warmup 1 \
     > "$ROOT/$OUT/prof_$CFG.log" 2>&1 || { tail -30 "$ROOT/$OUT/prof_$CFG.log"; exit 1; }
+# the rocpd databases are tens of MB each: keep the text summaries, drop the databases
+python3 "$ROOT/tools/rocpd_summary.py" stats "$ROOT/$OUT/prof_$CFG/${CFG}_results.db" \
+    > "$ROOT/$OUT/${CFG}_kernel_stats.csv" && rm -rf "$ROOT/$OUT/prof_$CFG"
 for PASS in "FETCH_SIZE" "WRITE_SIZE" "SQ_WAVE_CYCLES SQ_VALU_MFMA_BUSY_CYCLES SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_WAIT_ANY SQ_LDS_BANK_CONFLICT GRBM_GUI_ACTIVE"; do
   NAME=$(echo "$PASS" | cut -d' ' -f1)
   timeout -s KILL 600 rocprofv3 --pmc $PASS -d "$ROOT/$OUT/pmc_${CFG}_$NAME" -o "$CFG" -- \
       python3 "$ROOT/bench.py" --config "$CFG" $EXTRA --no-cpu --steps 1 --warmup 0 \
       > "$ROOT/$OUT/pmc_${CFG}_$NAME.log" 2>&1 || { tail -30 "$ROOT/$OUT/pmc_${CFG}_$NAME.log"; exit 1; }
+  python3 "$ROOT/tools/rocpd_summary.py" pmc "$ROOT/$OUT/pmc_${CFG}_$NAME/${CFG}_results.db" \
+      > "$ROOT/$OUT/${CFG}_pmc_$NAME.csv" && rm -rf "$ROOT/$OUT/pmc_${CFG}_$NAME"
 done
 cd "$ROOT"
-find "$OUT" -name '*.csv' | head -40
+ls "$OUT"
