@@ -78,6 +78,14 @@ COSMO_CONFIGS = {
 }
 
 
+BEAM_CONFIGS = {
+    # beam-head consumers of the generator -- name: (hex_spec, Nsrc, Nf, Nt, nmax, mmax)
+    # Fourier-Bessel basis of nmax radial x (2 mmax + 1) azimuthal modes
+    "beam": ((4, 7), 500, 16, 30, 8, 2),
+    "beams": ((3, 4), 60, 3, 4, 3, 1),
+}
+
+
 def synth_inputs(hex_spec, ns, nf, nt, outriggers=0):
     """Synthetic inputs of SURVEY section 8(d): hex array (14.6 m), random catalogue seed 0,
     100-120 MHz, LST 0.2-0.5 rad, Gaussian beam D = 14 m, gains (1+1j) + 0.05 N(0,1),
@@ -621,13 +629,124 @@ def cosmo_cpu_baseline(ant_pos, antpairs, freqs, times, g_ra, g_dec, g0, sigma, 
                        f"response build {t_resp:.2f}s not counted")}
 
 
+def main_beam(args, comm, rank, world, dev):
+    """Operator builds/s of the beam head's simulator consumers (per_antenna_beam_example.py:
+    118-260): one step = the sky contraction with the outer product of the Fourier-Bessel design
+    matrix (get_bess_sky_contraction) + the coefficient-to-visibility operator of every antenna
+    (get_bess_to_vis_from_contraction).  Frequency channels are independent and sharded over
+    ranks with no collective (each rank's channels are its own output)."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import per_ant_beam_sampler as bs
+    hex_spec, ns, nf, nt, nmax, mmax = BEAM_CONFIGS[args.config]
+    inp = synth_inputs(hex_spec, ns, nf, nt)
+    ant_pos = inp["ant_pos"]
+    nant = len(ant_pos)
+    fidx = np.array_split(np.arange(nf), world)[rank]
+    nf_loc = fidx.size
+    freqs_hz = inp["freqs"][fidx] * 1e6
+    fluxes = inp["fluxes"][:, fidx]
+    lsts = inp["times"]
+    nm = np.repeat(np.arange(1, nmax + 1), 2 * mmax + 1)
+    mm = np.tile(np.arange(-mmax, mmax + 1), nmax)
+    nc = nm.size
+    rng = np.random.RandomState(3)
+    bess = bs.get_bess_matr(nm, mm, rng.uniform(0.0, 1.0, (nt, ns)), rng.uniform(0.0, 2 * np.pi, (nt, ns)))
+    outer = torch.as_tensor(bs.get_bess_outer(bess), device=dev).contiguous()
+    coeffs = torch.as_tensor(rng.randn(nc, nf_loc, nant, 1, 1) + 1j * rng.randn(nc, nf_loc, nant, 1, 1),
+                             device=dev)
+    lat = -30.7215 * np.pi / 180.0
+
+    def one_step():
+        bsc = bs.get_bess_sky_contraction(outer, ant_pos, fluxes, inp["ra"], inp["dec"], freqs_hz,
+                                          lsts, latitude=lat)
+        ops = [bs.get_bess_to_vis_from_contraction(bsc, coeffs, nant, a) for a in range(nant)]
+        return bsc, ops
+
+    def sync():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        one_step()
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        bsc, ops = one_step()
+    sync()
+    elapsed = time.perf_counter() - t0
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if comm is not None:
+        comm.allreduce_(t_all, op="max")
+    elapsed = float(t_all.item())
+    # the contraction kernel alone, HIP events on the launch stream
+    from hydra_amd import _dev as dv
+    V = bs._uniform_voltages(ant_pos, fluxes, inp["ra"], inp["dec"], freqs_hz, lsts, lat)
+    out = dv.empty((nf_loc, nt, nant, nant, nc * nc), torch.complex128)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    reps = 3
+    e0.record()
+    for _ in range(reps):
+        dv.call("hydra_bess_sky_contraction", dv.ptr(V), nf_loc, nt, nant, ns, dv.ptr(outer), nc * nc,
+                dv.ptr(None), -1, dv.ptr(out), dv.stream_ptr())
+    e1.record()
+    torch.cuda.synchronize()
+    k_ms = e0.elapsed_time(e1) / reps
+    if rank != 0:
+        return
+    flops = 8.0 * nf_loc * nt * nant * nant * ns * nc * nc
+    achieved = flops / (k_ms * 1e-3) / 1e12
+    res = {
+        "metric": "beam-head operator builds/sec (sky contraction + per-antenna operators, whole job)",
+        "value": args.steps / elapsed, "unit": "builds/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"beam-head consumers ({args.config}): hex{hex_spec} = {nant} antennas, {ns} sources, "
+                         f"{nf} freqs x {nt} times, {nc} Fourier-Bessel modes ({nc * nc} basis pairs), "
+                         f"uniform-beam generator fused into the contraction, complex128"),
+            "parallelism": f"freq-sharded x{world}, no collective" if world > 1 else "single GPU",
+        },
+        "roofline": {
+            "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "kernel": "bess_contract_kernel (FP64 vector FMAs; the FP64 vector peak equals the matrix peak)",
+            "ms_per_launch": k_ms, "flops_per_launch": flops,
+        },
+        "cpu_baseline": None,
+    }
+    if not args.no_cpu:
+        from oracle import gcr_beam as ob
+        nf_s, nt_s = 1, min(nt, 2)
+        t0 = time.perf_counter()
+        ref = ob.get_bess_sky_contraction(bs.get_bess_outer(bess[:nt_s]), ant_pos, inp["fluxes"][:, :nf_s],
+                                          inp["ra"], inp["dec"], inp["freqs"][:nf_s] * 1e6, lsts[:nt_s],
+                                          latitude=lat)
+        cf = coeffs[:, :nf_s].cpu().numpy()
+        for a in range(nant):
+            ob.get_bess_to_vis_from_contraction(ref, cf, nant, a)
+        dt = time.perf_counter() - t0
+        res["cpu_baseline"] = {
+            "value": 1.0 / (dt * nf * nt / (nf_s * nt_s)), "unit": "builds/s",
+            "cores": len(os.sched_getaffinity(0)), "kind": "port",
+            "sample": (f"oracle (numpy restatement of get_bess_sky_contraction + "
+                       f"get_bess_to_vis_from_contraction for all antennas) on {nf_s} x {nt_s} of "
+                       f"{nf} x {nt} (freq x time) samples, {dt:.2f}s, scaled linearly"),
+        }
+        got = bsc[0, 0, 0, :nt_s].cpu().numpy()
+        res["parity_vs_oracle_slice"] = float(np.abs(got - ref[0, 0, 0]).max() / np.abs(ref).max())
+    print(json.dumps(res))
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=3)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--config", default="c2", choices=sorted(CONFIGS) + sorted(SH_CONFIGS) + sorted(GAIN_CONFIGS)
-                    + sorted(COSMO_CONFIGS))
+                    + sorted(COSMO_CONFIGS) + sorted(BEAM_CONFIGS))
     ap.add_argument("--no-cpu", action="store_true", help="skip the CPU baseline leg")
     ap.add_argument("--cg-tol", type=float, default=1e-8)
     ap.add_argument("--gram", default="auto", choices=["auto", "general"],
@@ -658,6 +777,8 @@ def main():
         return main_gain(args, comm, rank, world, dev)
     if args.config in COSMO_CONFIGS:
         return main_cosmo(args, comm, rank, world, dev)
+    if args.config in BEAM_CONFIGS:
+        return main_beam(args, comm, rank, world, dev)
 
     hex_spec, ns, nf, nt = CONFIGS[args.config]
     big = args.config in ("c5s", "c5")

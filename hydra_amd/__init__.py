@@ -9,6 +9,7 @@ of HydraRadio/Hydra, behind the Python API of the reference's modules:
     hydra_amd.gain_sampler    <->  hydra/gain_sampler.py
     hydra_amd.region_sampler  <->  hydra/region_sampler.py (projection operator, segmentation)
     hydra_amd.cosmo_sampler   <->  hydra/cosmo_sampler.py
+    hydra_amd.per_ant_beam_sampler <-> hydra/per_ant_beam_sampler.py (simulator consumers)
     hydra_amd.utils, .example <->  hydra/utils.py, hydra/example.py (hot-path helpers)
 
 Every arithmetic step runs in libhydra_hip.so (hand-written HIP kernels, C ABI in
@@ -19,9 +20,10 @@ from . import _lib
 
 _lib.load()          # fail loudly at import if the HIP library has not been built
 
-from . import (beams, cosmo_sampler, example, gain_sampler, linear_solver, ptsrc_sampler,  # noqa: E402,F401
-               region_sampler, sh_sampler, utils, vis_simulator)
+from . import (beams, cosmo_sampler, example, gain_sampler, linear_solver, per_ant_beam_sampler,  # noqa: E402,F401
+               ptsrc_sampler, region_sampler, sh_sampler, utils, vis_simulator)
 from .utils import *  # noqa: E402,F401,F403  (the reference re-exports utils: hydra/__init__.py:12)
 
-__all__ = ["beams", "cosmo_sampler", "example", "gain_sampler", "linear_solver", "ptsrc_sampler",
+__all__ = ["beams", "cosmo_sampler", "example", "gain_sampler", "linear_solver", "per_ant_beam_sampler",
+           "ptsrc_sampler",
            "region_sampler", "sh_sampler", "utils", "vis_simulator"]

@@ -497,7 +497,17 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 // The scaled voltages of 20 antennas are one LDS buffer; two buffers are filled alternately by
 // LDS-DMA (global_load_lds_dwordx4, no registers, no VALU) one phase ahead of the MFMA loop
 // that reads the other, so staging hides under the matrix work.
-constexpr int UCH = 20;  // antennas per LDS buffer (5 k-steps of 4)
+// Tile shape knobs (defaults measured best on config 2: 8 waves, 96 x 128, 20 antennas per buffer,
+// one workgroup per CU = 135 ms; the 4-wave 96 x 64 tile with two workgroups per CU and 12
+// antennas per buffer, -DHYDRA_K3_WC=2 -DHYDRA_K3_UCH=12, takes 151 ms: more barriers per (f,t)
+// and 43 % more staging traffic outweigh the overlap of one workgroup's barriers with the other).
+#ifndef HYDRA_K3_UCH
+#define HYDRA_K3_UCH 20
+#endif
+#ifndef HYDRA_K3_WC
+#define HYDRA_K3_WC 4
+#endif
+constexpr int UCH = HYDRA_K3_UCH;  // antennas per LDS buffer (k-steps of 4)
 
 // U[ft][a][s] = V[ft][a][s] * w_ft^(1/4) * |g_a,ft| for a < nant, 0 for the pad rows a >= nant.
 // same_beam: every antenna has the same |v_a,s| (one beam model), so
@@ -560,7 +570,11 @@ noise_uniform_kernel(const double* __restrict__ w, int nbl, int nft, double* __r
 // tile 96 (rows) x 128 (columns) per 8-wave workgroup, wave tile 48 x 32 (3 x 2 blocks,
 // 24 accumulators = 192 VGPRs).  Tiles form a 96 x 128 grid over the lower triangle; the tile
 // (ti, tj) is needed iff 96 ti + 95 >= 128 tj.
-constexpr int K3_TR = 96, K3_TC = 128, K3_W = K3_TR + K3_TC;   // LDS row: 224 complex
+constexpr int K3_WC = HYDRA_K3_WC;                 // waves along the columns (2 along the rows)
+constexpr int K3_THREADS = 2 * K3_WC * 64;
+constexpr int K3_TR = 96, K3_TC = 32 * K3_WC, K3_W = K3_TR + K3_TC;   // LDS row (complex)
+constexpr int K3_PIECES = UCH * K3_W / 64;         // 64-element DMA pieces per buffer
+static_assert(UCH % 4 == 0 && (UCH * K3_W) % 64 == 0, "LDS buffer = whole k-steps and DMA pieces");
 constexpr int K3_TILE = K3_TR * K3_TC;
 
 __host__ __device__ inline int k3_ncols(int ti, int nct) {   // column tiles needed in row tile ti
@@ -584,7 +598,7 @@ __device__ __forceinline__ void k3_tile_of(int p, int nct, int* ti, int* tj) {
 }
 
 template <bool SAMEBEAM>
-__global__ void __launch_bounds__(512, 1)
+__global__ void __launch_bounds__(K3_THREADS, K3_WC == 4 ? 1 : 2)
 gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int ntiles,
                        int ft_per_split, int qrow, double* __restrict__ slabs) {
   extern __shared__ __align__(16) unsigned char smem[];
@@ -595,7 +609,7 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
   int ti, tj;
   k3_tile_of(tile, (ns + K3_TC - 1) / K3_TC, &ti, &tj);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wr = wave >> 2, wc = wave & 3;
+  const int wr = wave / K3_WC, wc = wave % K3_WC;
   const int kr = lane >> 4, lc = lane & 15;
   int ft_begin = split * ft_per_split;
   int ft_end = ft_begin + ft_per_split;
@@ -610,9 +624,9 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
     int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
     const f64x2* src = U + ((size_t)ft * nantp) * ns;
 #pragma unroll
-    for (int i = 0; i < 9; ++i) {
-      int q = wave + 8 * i;
-      if (q < UCH * K3_W / 64) {
+    for (int i = 0; i < (K3_PIECES + 2 * K3_WC - 1) / (2 * K3_WC); ++i) {
+      int q = wave + 2 * K3_WC * i;
+      if (q < K3_PIECES) {
         int L = q * 64 + lane;
         int r = L / K3_W, col = L - r * K3_W;
         int a = min(c * UCH + r, nantp - 1);
@@ -982,11 +996,11 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   profile_record(0, st);
   if (same_beam) {
     if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel<true>), lds)) return rc;
-    gram_uniform_kernel<true><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles,
+    gram_uniform_kernel<true><<<ntiles * nsplit, K3_THREADS, lds, st>>>(U, nft, nantp, ns, ntiles,
                                                                     (int)per, nant, slabs);
   } else {
     if (int rc = reserve_lds(reinterpret_cast<const void*>(&gram_uniform_kernel<false>), lds)) return rc;
-    gram_uniform_kernel<false><<<ntiles * nsplit, 512, lds, st>>>(U, nft, nantp, ns, ntiles,
+    gram_uniform_kernel<false><<<ntiles * nsplit, K3_THREADS, lds, st>>>(U, nft, nantp, ns, ntiles,
                                                                      (int)per, -1, slabs);
   }
   profile_record(1, st);

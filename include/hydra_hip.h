@@ -111,6 +111,27 @@ int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const i
                       const int32_t* bl_j, int nbl, const int32_t* seg_host, const int32_t* seg,
                       int nreg, double* out, void* stream);
 
+/* Beam-head consumer of the generator: per-source visibilities of a uniform-beam array made
+ * Hermitian in the antenna pair (autos doubled) and contracted over sources with the
+ * Fourier-Bessel matrices, without forming the per-source cube:
+ *   out[f,t,a,A,q] = sum_s M_s[a,A] B[t,s,q],  M_s[a,A] = conj(V_a,s) V_A,s r_s with r = ref[f,t,s] for
+ *   a < A, conj(ref) for a > A, and M_s[a,a] = 2|V_a,s|^2 Re ref (ref scales the upper triangle first)
+ * V (Nf,Nt,Nant,Ns) c128 from hydra_voltages with a uniform beam; B (Nt,Ns,Q) c128 (Q = Nc^2 for
+ * the outer product of the design matrix, Nc for a power-beam/reference contraction); ref
+ * (Nf,Nt,Ns) c128 or NULL; out (Nf,Nt,Nant,Nant,Q) c128.   per_ant_beam_sampler.py:385-422
+ * row >= 0: only out[f,t,A,row,q] (the column of the sampled antenna) is formed, into an
+ * (Nf,Nt,Nant,Q) array -- what get_bess_to_vis needs (per_ant_beam_sampler.py:468-583).       */
+int hydra_bess_sky_contraction(const double* V, int nf, int nt, int nant, int ns, const double* B,
+                               int nq, const double* ref, int row, double* out, void* stream);
+
+/* out[f,t,k,B] = sum_b conj(coef[b,f,A_k]) C[f,t,A_k,samp,b,B], A_k the k-th antenna != samp:
+ * the operator from the sampled antenna's beam coefficients to visibilities
+ * (get_bess_to_vis_from_contraction, per_ant_beam_sampler.py:453-463).  C (Nf,Nt,Nant,Nant,Nc,NB)
+ * c128, or with col_only != 0 the column alone (Nf,Nt,Nant,Nc,NB); coef (Nc,Nf,Nant) c128; NB = Nc,
+ * or 1 for a reference-beam contraction; out (Nf,Nt,Nant-1,NB) c128.                          */
+int hydra_bess_to_vis(const double* C, const double* coef, int nf, int nt, int nant, int nc, int nb,
+                      int samp, int col_only, double* out, void* stream);
+
 /* ---- GCR operator ---------------------------------------------------------------- */
 
 /* Per-row factors for rows r = (b,f,t) in (Nbl,Nf,Nt) order:

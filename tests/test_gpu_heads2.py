@@ -335,3 +335,70 @@ def test_symmetric_half_read_matvec_matches_numpy(hy, n, nb):
         _dev.call("hydra_symv_batched", _dev.ptr(_dev.f64(A2)), n, nb, _dev.ptr(xd), _dev.ptr(yd), 0,
                   _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
         assert relerr(yd.cpu().numpy(), ref) < 1e-13
+
+
+# ------------------------------------------------------------------ beam-head consumers
+
+def test_beam_head_helpers_match_reference_golden(hy):
+    bs = hy.per_ant_beam_sampler
+    g = load_golden("beam.npz")
+    assert np.array_equal(bs.get_ant_inds(2, 5), g["keep"])
+    bess = bs.get_bess_matr(g["nmodes"], g["mmodes"], g["rho"], g["phi"])
+    assert np.array_equal(bess, g["bess"])
+    assert np.array_equal(bs.get_bess_outer(bess), g["outer"])
+    tr = bs.get_bess_to_vis_from_contraction(g["bsc"], g["coeffs"], 5, 2)
+    assert isinstance(tr, np.ndarray) and tr.shape == g["trans"].shape
+    assert relerr(tr, g["trans"]) < 1e-13
+    tr = bs.get_bess_to_vis_from_contraction(g["bsc_ref"], g["coeffs"], 5, 2, ref_contraction=True)
+    assert tr.shape == g["trans_ref"].shape and relerr(tr, g["trans_ref"]) < 1e-13
+    sub = bs.select_subarr(g["bsc"], 2, 5)
+    assert sub.shape == g["bsc"][:, :, :, :, g["keep"], 2].shape
+
+
+@pytest.mark.parametrize("hex_spec,ns,nf,nt,nmax", [((2, 3), 23, 2, 3, 2), ((3, 4), 150, 3, 2, 3),
+                                                   ((4, 7), 70, 1, 2, 4)])
+def test_bess_sky_contraction_and_operator_match_oracle(hy, hex_spec, ns, nf, nt, nmax):
+    from oracle import gcr_beam as ob, helpers
+    bs = hy.per_ant_beam_sampler
+    rng = np.random.RandomState(ns)
+    ant_pos = helpers.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    np.random.seed(ns)
+    ra, dec, amps = helpers.generate_random_ptsrc_catalogue(ns, (0.0, 2 * np.pi), (-1.4, 0.6))
+    freqs = np.linspace(100.0, 120.0, nf)
+    fluxes = helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    lsts = np.linspace(0.2, 0.5, nt)
+    nm = np.repeat(np.arange(1, nmax + 1), 3)
+    mm = np.tile(np.array([0, 1, -1]), nmax)
+    nc = nm.size
+    bess = ob.get_bess_matr(nm, mm, rng.uniform(0, 1, (nt, ns)), rng.uniform(0, 6.28, (nt, ns)))
+    outer = ob.get_bess_outer(bess)
+    ref = ob.get_bess_sky_contraction(outer, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, latitude=LAT)
+    out = bs.get_bess_sky_contraction(outer, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts,
+                                      latitude=LAT)
+    assert isinstance(out, np.ndarray) and out.shape == ref.shape == (1, 1, nf, nt, nant, nant, nc, nc)
+    assert relerr(out, ref) < OP_TOL
+    # Hermitian in (antenna pair, basis pair); autos doubled
+    assert relerr(out, out.transpose(0, 1, 2, 3, 5, 4, 7, 6).conj()) < 1e-13
+    # power-beam form with a reference response
+    rbr = rng.uniform(0.2, 1.0, (nf, nt, ns)) + 1j * rng.uniform(-0.1, 0.1, (nf, nt, ns))
+    ref2 = ob.get_bess_sky_contraction(bess, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts,
+                                       latitude=LAT, outer=False, ref_beam_response=rbr)
+    out2 = bs.get_bess_sky_contraction(bess, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts,
+                                       latitude=LAT, outer=False, ref_beam_response=rbr)
+    assert out2.shape == ref2.shape and relerr(out2, ref2) < OP_TOL
+    # operator for one antenna, both routes
+    coeffs = rng.randn(nc, nf, nant, 1, 1) + 1j * rng.randn(nc, nf, nant, 1, 1)
+    samp = nant // 2
+    tr_ref = ob.get_bess_to_vis_from_contraction(ref, coeffs, nant, samp)
+    tr = bs.get_bess_to_vis_from_contraction(out, coeffs, nant, samp)
+    assert relerr(tr, tr_ref) < OP_TOL
+    tr_direct = bs.get_bess_to_vis(bess, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, coeffs, samp,
+                                   latitude=LAT)
+    tr_direct_ref = ob.get_bess_to_vis(bess, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, coeffs,
+                                       samp, latitude=LAT)
+    assert tr_direct.shape == tr_direct_ref.shape == (1, 1, nf, nt, nant - 1, nc)
+    assert relerr(tr_direct, tr_direct_ref) < OP_TOL
+    assert relerr(tr_direct, tr) < 1e-12
+    with pytest.raises(NotImplementedError):
+        bs.get_bess_sky_contraction(outer, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, polarized=True)

@@ -223,3 +223,41 @@ def test_region_segmentation_matches_reference():
         for q, ix in enumerate(idx):
             assert np.array_equal(ix, g[f"n{nreg}_{q}"])
         assert sum(ix.size for ix in idx) == g["ra"].size
+
+
+# ---------------------------------------------------------------- beam-head consumers
+
+def test_beam_head_helpers_match_reference():
+    from oracle import gcr_beam as ob
+    g = load_golden("beam.npz")
+    assert np.array_equal(ob.get_ant_inds(2, 5), g["keep"])
+    bess = ob.get_bess_matr(g["nmodes"], g["mmodes"], g["rho"], g["phi"])
+    assert np.array_equal(bess, g["bess"])
+    assert np.array_equal(ob.get_bess_outer(bess), g["outer"])
+    tr = ob.get_bess_to_vis_from_contraction(g["bsc"], g["coeffs"], 5, 2)
+    assert tr.shape == g["trans"].shape and relerr(tr, g["trans"]) < TIGHT
+    tr = ob.get_bess_to_vis_from_contraction(g["bsc_ref"], g["coeffs"], 5, 2, ref_contraction=True)
+    assert tr.shape == g["trans_ref"].shape and relerr(tr, g["trans_ref"]) < TIGHT
+
+
+def test_beam_head_two_routes_to_the_operator_agree():
+    """get_bess_to_vis == get_bess_outer -> get_bess_sky_contraction -> ..._from_contraction
+    (the reference documents the former as the slower alternative of the latter)."""
+    from oracle import gcr_beam as ob, helpers
+    rng = np.random.RandomState(5)
+    ant_pos = helpers.build_hex_array(hex_spec=(2, 3), d=14.6)
+    nant = len(ant_pos)
+    np.random.seed(4)
+    ra, dec, amps = helpers.generate_random_ptsrc_catalogue(12, (0.0, 1.0), (-0.6, 0.4))
+    freqs = np.linspace(100.0, 110.0, 2)
+    fluxes = helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    lsts = np.linspace(0.2, 0.5, 3)
+    nm, mm = np.array([1, 2, 1, 2]), np.array([0, 0, 1, 1])
+    bess = ob.get_bess_matr(nm, mm, rng.uniform(0, 1, (3, 12)), rng.uniform(0, 6, (3, 12)))
+    coeffs = rng.randn(4, 2, nant, 1, 1) + 1j * rng.randn(4, 2, nant, 1, 1)
+    bsc = ob.get_bess_sky_contraction(ob.get_bess_outer(bess), ant_pos, fluxes, ra, dec,
+                                      freqs * 1e6, lsts)
+    a = ob.get_bess_to_vis_from_contraction(bsc, coeffs, nant, 3)
+    b = ob.get_bess_to_vis(bess, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, coeffs, 3)
+    assert a.shape == b.shape == (1, 1, 2, 3, nant - 1, 4)
+    assert relerr(a, b) < 1e-12
