@@ -123,7 +123,7 @@ def main(argv=None):
         comm.Bcast(cat, root=0)
     ra, dec, ptsrc_amps = cat
     fluxes_chunk = hydra.get_flux_from_ptsrc_amp(ptsrc_amps, freq_chunk, -2.7)
-    beams = [hydra.beams.GaussianBeam(diameter=14.0) for _ in ants]
+    beams = hydra.example.example_beams(args.beam_type, len(ants))
 
     # ---- operators (example.py:507-523, 597-624): factored source operator, SH response
     t0 = time.time()

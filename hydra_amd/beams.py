@@ -21,7 +21,13 @@ HYDRA_BEAM_GAUSS_DIAMETER = 0
 HYDRA_BEAM_GAUSS_SIGMA = 1
 HYDRA_BEAM_UNIFORM = 2
 HYDRA_BEAM_VALUES = 3
-HYDRA_BEAM_NPARAMS = 4
+HYDRA_BEAM_POLY = 4
+HYDRA_BEAM_NPARAMS = 32
+HYDRA_BEAM_POLY_MAXCOEF = HYDRA_BEAM_NPARAMS - 3
+
+
+def _pad(params):
+    return list(params) + [0.0] * (HYDRA_BEAM_NPARAMS - len(params))
 
 
 class GaussianBeam:
@@ -45,9 +51,9 @@ class GaussianBeam:
 
     def hip_spec(self):
         if self.diameter is not None:
-            return HYDRA_BEAM_GAUSS_DIAMETER, [float(self.diameter), 0.0, 0.0, 0.0]
+            return HYDRA_BEAM_GAUSS_DIAMETER, _pad([float(self.diameter)])
         ref = 0.0 if self.reference_frequency is None else float(self.reference_frequency)
-        return HYDRA_BEAM_GAUSS_SIGMA, [float(self.sigma), ref, float(self.spectral_index), 0.0]
+        return HYDRA_BEAM_GAUSS_SIGMA, _pad([float(self.sigma), ref, float(self.spectral_index)])
 
     def get_sigmas(self, freq_array):
         freq_array = np.asarray(freq_array, dtype=np.float64)
@@ -71,10 +77,41 @@ class UniformBeam:
     polarization_array = np.array([-5])
 
     def hip_spec(self):
-        return HYDRA_BEAM_UNIFORM, [0.0, 0.0, 0.0, 0.0]
+        return HYDRA_BEAM_UNIFORM, _pad([])
 
     def compute_response(self, *, az_array, za_array, freq_array, **_unused):
         return np.ones((1, 1, np.atleast_1d(freq_array).size, np.asarray(za_array).size))
+
+
+class PolyBeam:
+    """Chebyshev-polynomial beam of ``hera_sim.beams.PolyBeam`` (hydra/example.py:143-168):
+    E(za, nu) = T(x) / T(-1) with x = 2 sin(za / (nu / ref_freq)**spectral_index) - 1 and T the
+    Chebyshev series with coefficients ``beam_coeffs``; the power beam is E**2.  Evaluated inside
+    the generator kernel.  hera_sim is not installed here, so the formula restates its published
+    definition: PARITY UNPINNED (as for the other third-party beams)."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, beam_coeffs, spectral_index=0.0, ref_freq=1.0e8):
+        self.beam_coeffs = np.atleast_1d(np.asarray(beam_coeffs, dtype=np.float64))
+        if not 1 <= self.beam_coeffs.size <= HYDRA_BEAM_POLY_MAXCOEF:
+            raise ValueError(f"PolyBeam takes 1..{HYDRA_BEAM_POLY_MAXCOEF} coefficients")
+        self.spectral_index = float(spectral_index)
+        self.ref_freq = float(ref_freq)
+
+    def hip_spec(self):
+        return HYDRA_BEAM_POLY, _pad([self.ref_freq, self.spectral_index, float(self.beam_coeffs.size)]
+                                     + [float(c) for c in self.beam_coeffs])
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        from numpy.polynomial.chebyshev import chebval
+        za = np.asarray(za_array, dtype=np.float64)
+        fscale = (np.atleast_1d(freq_array) / self.ref_freq) ** self.spectral_index
+        x = 2.0 * np.sin(za[None, :] / fscale[:, None]) - 1.0
+        e = chebval(x, self.beam_coeffs) / chebval(-1.0, self.beam_coeffs)
+        return (e ** 2)[None, None]
 
 
 def check_beams(beams, polarized=False):

@@ -125,6 +125,33 @@ voltages_kernel(const double* __restrict__ antpos, int nant, const double* __res
       power = exp(-(za * za) / (sigma * sigma));
     } else if (beam_kind == HYDRA_BEAM_UNIFORM) {
       power = 1.0;
+    } else if (beam_kind == HYDRA_BEAM_POLY) {
+      // E = T(x) / T(-1), x = 2 sin(za / (nu/nu_ref)^index) - 1, T a Chebyshev series summed by
+      // Clenshaw's recurrence (numpy.polynomial.chebyshev.chebval); power = E^2
+      int nco = (int)prm[2];
+      const double* cf = prm + 3;
+      double fscale = pow(freq / prm[0], prm[1]);
+      double x = 2.0 * sin(za / fscale) - 1.0;
+      double ev[2];
+#pragma unroll
+      for (int w = 0; w < 2; ++w) {
+        double xx = w ? -1.0 : x;
+        double v;
+        if (nco == 1) {
+          v = cf[0];
+        } else {
+          double c0 = cf[nco - 2], c1 = cf[nco - 1], x2 = 2.0 * xx;
+          for (int i = 3; i <= nco; ++i) {
+            double tmp = c0;
+            c0 = cf[nco - i] - c1;
+            c1 = tmp + c1 * x2;
+          }
+          v = c0 + c1 * xx;
+        }
+        ev[w] = v;
+      }
+      double e = ev[0] / ev[1];
+      power = e * e;
     } else {
       power = beam_vals[(((size_t)b * nf + f) * nt + t) * ns + s];
     }
@@ -385,7 +412,7 @@ int hydra_voltages(const double* antpos, int nant, const double* freqs_hz, int n
                   "hydra_voltages: sizes must be positive (nant=%d nf=%d nt=%d ns=%d nbeam=%d)",
                   nant, nf, nt, ns, nbeam);
   HYDRA_CHECK_ARG(nt <= 65535 && nf <= 65535, "hydra_voltages: nt, nf must be <= 65535");
-  HYDRA_CHECK_ARG(beam_kind >= 0 && beam_kind <= HYDRA_BEAM_VALUES,
+  HYDRA_CHECK_ARG(beam_kind >= 0 && beam_kind <= HYDRA_BEAM_POLY,
                   "hydra_voltages: unknown beam_kind %d", beam_kind);
   HYDRA_CHECK_ARG(beam_kind != HYDRA_BEAM_VALUES || beam_vals,
                   "hydra_voltages: beam_vals required for HYDRA_BEAM_VALUES");

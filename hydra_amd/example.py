@@ -4,7 +4,7 @@ Random catalogue and example simulation used by the driver and the tests -- drop
 """
 import numpy as np
 
-from .beams import GaussianBeam
+from .beams import GaussianBeam, PolyBeam
 from .utils import build_hex_array, extract_vis_from_sim, get_flux_from_ptsrc_amp
 from .vis_simulator import simulate_vis
 
@@ -24,12 +24,29 @@ def generate_random_ptsrc_catalogue(Nptsrc, ra_bounds, dec_bounds, logflux_bound
     return ra, dec, ptsrc_amps
 
 
+#: Chebyshev coefficients of the PolyBeam fitted to the HERA Fagnoni beam (hydra/example.py:145-164)
+HERA_POLYBEAM_COEFFS = [
+    0.29778665, -0.44821433, 0.27338272, -0.10030698, -0.01195859, 0.06063853, -0.04593295,
+    0.0107879, 0.01390283, -0.01881641, -0.00177106, 0.01265177, -0.00568299, -0.00333975,
+    0.00452368, 0.00151808, -0.00593812, 0.00351559,
+]
+
+
+def example_beams(beam_type, nants):
+    """One beam object per antenna as the reference's example builds them
+    (hydra/example.py:142-172): the HERA PolyBeam for a ``beam_type`` containing 'polybeam',
+    else a 14 m Gaussian."""
+    if "polybeam" in beam_type.lower():
+        return [PolyBeam(HERA_POLYBEAM_COEFFS, spectral_index=-0.6975, ref_freq=1.0e8)
+                for _ in range(nants)]
+    return [GaussianBeam(diameter=14.0) for _ in range(nants)]
+
+
 def run_example_simulation(times, freqs, output_dir, ra, dec, ptsrc_amps, array_latitude,
                            beam_type="gaussian", hex_array=(3, 4)):
     """Example visibility simulation on a hexagonal array (hydra/example.py:75-198).
     ``freqs`` in MHz, ``times`` LSTs in rad.  Returns (model0 (Nbl,Nf,Nt), fluxes, beams,
-    (ants, ant_pos, antpairs, ants1, ants2)).  Only the Gaussian beam of the reference's
-    default is built in (the 'polybeam' option needs hera_sim)."""
+    (ants, ant_pos, antpairs, ants1, ants2))."""
     hex_array = tuple(hex_array)
     assert len(hex_array) == 2, "hex-array argument must have length 2."
     ant_pos = build_hex_array(hex_spec=hex_array, d=14.6)
@@ -37,9 +54,7 @@ def run_example_simulation(times, freqs, output_dir, ra, dec, ptsrc_amps, array_
     antpairs = [(i, j) for i in range(len(ants)) for j in range(i, len(ants)) if i != j]
     ants1, ants2 = list(zip(*antpairs))
     fluxes = get_flux_from_ptsrc_amp(ptsrc_amps, freqs, -2.7)
-    if "polybeam" in beam_type.lower():
-        raise NotImplementedError("PolyBeam (hera_sim) is not available; use beam_type='gaussian'")
-    beams = [GaussianBeam(diameter=14.0) for _ in ants]
+    beams = example_beams(beam_type, len(ants))
     sim = simulate_vis(ants=ant_pos, fluxes=fluxes, ra=ra, dec=dec, freqs=freqs * 1e6, lsts=times,
                        beams=beams, polarized=False, precision=2, latitude=array_latitude,
                        use_feed="x")

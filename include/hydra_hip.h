@@ -39,7 +39,10 @@ extern "C" {
 #define HYDRA_BEAM_GAUSS_SIGMA 1    /* params: [sigma_rad, ref_freq_hz (0=none), index]  */
 #define HYDRA_BEAM_UNIFORM 2        /* params: unused                                    */
 #define HYDRA_BEAM_VALUES 3         /* beam_vals (Nbeam,Nf,Nt,Ns) power values given     */
-#define HYDRA_BEAM_NPARAMS 4        /* doubles per beam in beam_params                   */
+#define HYDRA_BEAM_POLY 4           /* Chebyshev polynomial beam (hera_sim PolyBeam, hydra/example.py:
+                                       143-168): params [ref_freq_hz, spectral_index, ncoef, c_0 .. ] */
+#define HYDRA_BEAM_NPARAMS 32       /* doubles per beam in beam_params                   */
+#define HYDRA_BEAM_POLY_MAXCOEF 29  /* = HYDRA_BEAM_NPARAMS - 3                          */
 
 const char* hydra_last_error(void);
 int hydra_abi_version(void);

@@ -59,6 +59,30 @@ class GaussianBeam:
         return power[np.newaxis, np.newaxis, :, :]
 
 
+class PolyBeam:
+    """``hera_sim.beams.PolyBeam`` (hydra/example.py:143-168; hera_sim is unpinned in
+    requirements.txt and not installed: PARITY UNPINNED, restated from its published definition).
+    E-field: chebval(x, coeffs) / chebval(-1, coeffs), x = 2 sin(za / fscale) - 1,
+    fscale = (nu / ref_freq)**spectral_index, i.e. normalised to 1 at zenith; power = E**2."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, beam_coeffs, spectral_index=0.0, ref_freq=1.0e8):
+        self.beam_coeffs = np.asarray(beam_coeffs, dtype=np.float64)
+        self.spectral_index = spectral_index
+        self.ref_freq = ref_freq
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        from numpy.polynomial.chebyshev import chebval
+        za = np.asarray(za_array, dtype=np.float64)
+        fscale = (np.atleast_1d(freq_array) / self.ref_freq) ** self.spectral_index
+        x = 2.0 * np.sin(za[np.newaxis, :] / fscale[:, np.newaxis]) - 1.0
+        efield = chebval(x, self.beam_coeffs) / chebval(-1.0, self.beam_coeffs)
+        return (efield ** 2)[np.newaxis, np.newaxis, :, :]
+
+
 class UniformBeam:
     """Unit response everywhere (pyuvdata ``UniformBeam``)."""
 

@@ -402,3 +402,42 @@ def test_bess_sky_contraction_and_operator_match_oracle(hy, hex_spec, ns, nf, nt
     assert relerr(tr_direct, tr) < 1e-12
     with pytest.raises(NotImplementedError):
         bs.get_bess_sky_contraction(outer, ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, polarized=True)
+
+
+# ------------------------------------------------------------------ PolyBeam
+
+def test_polybeam_generator_matches_oracle(hy):
+    """The Chebyshev beam of hydra/example.py:143-168 evaluated in the generator kernel against
+    the oracle's numpy.chebval restatement (formula parity unpinned: hera_sim is not installed),
+    plus the host-side compute_response used when beams of several kinds are mixed."""
+    from oracle import beams as obeams, helpers, response
+    coeffs = hy.example.HERA_POLYBEAM_COEFFS
+    ant_pos = helpers.build_hex_array(hex_spec=(2, 3), d=14.6)
+    nant = len(ant_pos)
+    np.random.seed(9)
+    ra, dec, amps = helpers.generate_random_ptsrc_catalogue(80, (0.0, 2 * np.pi), (-1.5, 0.9))
+    freqs = np.linspace(100.0, 200.0, 5)
+    fluxes = helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    lsts = np.linspace(0.1, 2.0, 4)
+    ob = [obeams.PolyBeam(coeffs, spectral_index=-0.6975, ref_freq=1.0e8) for _ in range(nant)]
+    hb = hy.example.example_beams("polybeam", nant)
+    assert type(hb[0]).__name__ == "PolyBeam"
+    ref = response.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, beams=ob,
+                                           latitude=LAT)
+    out = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, lsts,
+                                                   beams=hb, latitude=LAT)
+    assert relerr(out, ref) < OP_TOL
+    za = np.linspace(0.0, 1.5, 50)
+    assert relerr(hb[0].compute_response(az_array=0 * za, za_array=za, freq_array=freqs * 1e6),
+                  ob[0].compute_response(az_array=0 * za, za_array=za, freq_array=freqs * 1e6)) < 1e-15
+    assert abs(hb[0].compute_response(az_array=[0.0], za_array=[0.0], freq_array=[1.5e8])[0, 0, 0, 0]
+               - 1.0) < 1e-14
+    # mixed kinds go through the host value table
+    mix = [hb[0]] + [hy.beams.GaussianBeam(diameter=14.0) for _ in range(nant - 1)]
+    omix = [ob[0]] + [obeams.GaussianBeam(14.0) for _ in range(nant - 1)]
+    ref = response.simulate_vis(ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, beams=omix, latitude=LAT)
+    out = hy.vis_simulator.simulate_vis(ant_pos, fluxes, ra, dec, freqs * 1e6, lsts, beams=mix,
+                                        latitude=LAT)
+    assert relerr(out, ref) < OP_TOL
+    with pytest.raises(ValueError):
+        hy.beams.PolyBeam(np.ones(40))
