@@ -194,6 +194,143 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   }
 }
 
+// ---- R^H z in antenna space on the matrix cores -------------------------------------------------
+// sum_b Re(conj(conj(V_i) V_j) z_b) = Re sum_i V_i conj(W_i),  W = Zc V,  Zc[i][j] = sum of conj(z_b)
+// over the baselines b = (i, j): per (f,t) a (Nant x Nant) x (Nant x Ns) complex product instead of
+// Nbl pair products per source -- 4 real MFMAs per 16 x 4 block of Zc (blocks without a baseline
+// are skipped: the upper-triangular pair list of an array leaves ~60 %), then a dot product with
+// the voltages the lane already holds as MFMA B operands (the D-layout row 16 rb + kr + 4 g of a lane
+// is exactly the antenna of its B operand of k-step 4 rb + g).  Zc is scattered into LDS from the
+// transposed z, double buffered, one barrier per (f,t).  Nant <= 16 NR <= 64.
+template <int NR>
+__global__ void __launch_bounds__(256, 2)
+adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
+                      const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
+                      const f64x2* __restrict__ zt, int ft_per_split, double* __restrict__ partial) {
+  constexpr int NK = 4 * NR;            // k-steps of 4 antennas
+  constexpr int S = 4 * NK + 1;         // LDS row stride of Zc (complex elements), odd
+  constexpr int MAXB = (16 * NR * (16 * NR + 1) / 2 + 255) / 256;   // baselines per thread
+  extern __shared__ __align__(16) unsigned char smem[];
+  f64x2* s_z = reinterpret_cast<f64x2*>(smem);                       // [2][16 NR][S]
+  int* s_mask = reinterpret_cast<int*>(s_z + 2 * 16 * NR * S);       // [NR] bit kk set: block used
+  int* s_cnt = reinterpret_cast<int*>(s_z);   // [16 NR][16 NR] pair counts, prologue only (aliases Zc)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int kr = lane >> 4, lc = lane & 15;
+  const int s = (blockIdx.x * 4 + wave) * 16 + lc;
+  const int ft0 = blockIdx.y * ft_per_split;
+  const int ft1 = min(ft0 + ft_per_split, nft);
+
+  // ---- prologue: zero both Zc buffers, note which blocks hold a baseline, look for duplicates
+  for (int e = tid; e < 16 * NR * 16 * NR; e += 256) s_cnt[e] = 0;
+  if (tid < NR) s_mask[tid] = 0;
+  __syncthreads();
+  int pos[MAXB];
+  bool dup = false;
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    int b = tid + 256 * q;
+    pos[q] = -1;
+    if (b < nbl) {
+      int i = bl_i[b], j = bl_j[b];
+      pos[q] = i * S + j;
+      atomicOr(&s_mask[i >> 4], 1 << (j >> 2));
+      if (atomicAdd(&s_cnt[i * 16 * NR + j], 1) > 0) dup = true;
+    }
+  }
+  const bool any_dup = __syncthreads_or(dup);
+  int mask[NR];
+#pragma unroll
+  for (int rb = 0; rb < NR; ++rb) mask[rb] = s_mask[rb];
+  for (int e = tid; e < 2 * 16 * NR * S; e += 256) s_z[e] = f64x2{0.0, 0.0};
+  __syncthreads();
+
+  auto load_z = [&](int ft, f64x2 (&zr)[MAXB]) {
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+      int b = tid + 256 * q;
+      zr[q] = (b < nbl) ? zt[(size_t)ft * nbl + b] : f64x2{0.0, 0.0};
+    }
+  };
+  auto store_z = [&](int buf, const f64x2 (&zr)[MAXB]) {
+    f64x2* zb = s_z + buf * 16 * NR * S;
+    if (!any_dup) {
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q)
+        if (pos[q] >= 0) zb[pos[q]] = f64x2{zr[q].x, -zr[q].y};
+    } else {   // repeated pairs: clear the used entries, then add (two extra barriers)
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q)
+        if (pos[q] >= 0) zb[pos[q]] = f64x2{0.0, 0.0};
+      __syncthreads();
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q)
+        if (pos[q] >= 0) {
+          double* zd = reinterpret_cast<double*>(zb + pos[q]);
+          atomicAdd(zd, zr[q].x);
+          atomicAdd(zd + 1, -zr[q].y);
+        }
+    }
+  };
+  auto load_v = [&](int ft, f64x2 (&v)[NK]) {
+    const f64x2* vft = V + (size_t)ft * nant * ns;
+#pragma unroll
+    for (int kk = 0; kk < NK; ++kk) {
+      int a = 4 * kk + kr;
+      v[kk] = (a < nant && s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
+    }
+  };
+
+  double acc = 0.0;
+  if (ft0 < ft1) {
+    f64x2 zr[MAXB], v[NK], vn[NK];
+    load_z(ft0, zr);
+    load_v(ft0, v);
+    store_z(0, zr);
+    for (int ft = ft0; ft < ft1; ++ft) {
+      const int buf = (ft - ft0) & 1;
+      __syncthreads();   // Zc[buf] is complete; nobody reads Zc[buf ^ 1] any more
+      const bool more = ft + 1 < ft1;
+      if (more) {        // next sample's z and voltages travel while this one is multiplied
+        load_z(ft + 1, zr);
+        load_v(ft + 1, vn);
+      }
+      const f64x2* zb = s_z + buf * 16 * NR * S;
+      f64x4 wx[NR], wy[NR];
+#pragma unroll
+      for (int rb = 0; rb < NR; ++rb) {
+        wx[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        wy[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      }
+#pragma unroll
+      for (int kk = 0; kk < NK; ++kk) {
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb) {
+          if (mask[rb] & (1 << kk)) {   // uniform over the workgroup
+            f64x2 zc = zb[(rb * 16 + lc) * S + 4 * kk + kr];
+            wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc.x, v[kk].x, wx[rb], 0, 0, 0);
+            wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-zc.y, v[kk].y, wx[rb], 0, 0, 0);
+            wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc.y, v[kk].x, wy[rb], 0, 0, 0);
+            wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc.x, v[kk].y, wy[rb], 0, 0, 0);
+          }
+        }
+      }
+#pragma unroll
+      for (int rb = 0; rb < NR; ++rb)
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          acc += wx[rb][g] * v[4 * rb + g].x + wy[rb][g] * v[4 * rb + g].y;
+      if (more) {
+        store_z(buf ^ 1, zr);
+#pragma unroll
+        for (int kk = 0; kk < NK; ++kk) v[kk] = vn[kk];
+      }
+    }
+  }
+  acc += __shfl_xor(acc, 16, 64);
+  acc += __shfl_xor(acc, 32, 64);
+  if (kr == 0 && s < ns) partial[(size_t)blockIdx.y * ns + s] = acc;
+}
+
 // (nbl, nft) -> (nft, nbl) complex transpose so a workgroup reads one (f,t) slice contiguously
 __global__ void __launch_bounds__(256)
 ctranspose_kernel(const f64x2* __restrict__ in, int nbl, int nft, f64x2* __restrict__ out) {
@@ -270,6 +407,9 @@ static void adjoint_plan(long long m, int ns, int* nchunk, long long* rows_per_c
   *rows_per_chunk = per;
   (void)ns;
 }
+
+// test hook: 0 forces the pair-loop kernels (hydra_debug_adjoint_mfma)
+static int g_adjoint_mfma = 1;
 
 static void adjoint_V_plan(int nft, int ns, int* nsplit, int* per) {
   int chunks = (ns + 63) / 64;   // (sized for the 64-wide kernel; the 16-wide one just has more chunks)
@@ -397,6 +537,12 @@ int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const i
                         out, seg, nreg, stream);
 }
 
+int hydra_debug_adjoint_mfma(int enable) {
+  int old = g_adjoint_mfma;
+  g_adjoint_mfma = enable ? 1 : 0;
+  return old;
+}
+
 size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns) {
   if (nf <= 0 || nt <= 0 || nbl <= 0 || ns <= 0) return 0;
   int nsplit, per;
@@ -428,7 +574,23 @@ int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int
   ctranspose_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const f64x2*>(z), nbl, nft, zt);
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V(transpose)");
   const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
-  if (wide) {
+  if (nant <= 64 && g_adjoint_mfma) {   // antenna-space product on the matrix cores
+    int nr = (nant + 15) / 16;
+    dim3 grid((ns + 63) / 64, nsplit);
+#define HYDRA_ADJ_MFMA(NR_)                                                                      \
+    {                                                                                            \
+      size_t lds = (size_t)2 * 16 * NR_ * (16 * NR_ + 1) * 16 + 16;                               \
+      if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_mfma_kernel<NR_>), lds)) \
+        return rc_lds;                                                                           \
+      adjoint_V_mfma_kernel<NR_><<<grid, 256, lds, st>>>(Vp, nft, nant, ns, bl_i, bl_j, nbl, zt,   \
+                                                         per, partial);                          \
+    }
+    if (nr == 1) HYDRA_ADJ_MFMA(1)
+    else if (nr == 2) HYDRA_ADJ_MFMA(2)
+    else if (nr == 3) HYDRA_ADJ_MFMA(3)
+    else HYDRA_ADJ_MFMA(4)
+#undef HYDRA_ADJ_MFMA
+  } else if (wide) {
     if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_kernel<64>), lds64)) return rc_lds;
     dim3 grid((ns + 63) / 64, nsplit);
     adjoint_V_kernel<64><<<grid, 256, lds64, st>>>(Vp, nft, nant, ns, bl_i, bl_j, nbl, zt, per, partial);

@@ -226,6 +226,10 @@ int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32
                   const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
                   double* out, void* stream);
 size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns);
+/* Test hook: hydra_adjoint_V forms R^H z in antenna space on the matrix cores when Nant <= 64
+ * (default) and with the pair-loop kernel otherwise; enable = 0 forces the pair loop.  Returns the
+ * previous setting.  No counterpart in the reference.                                        */
+int hydra_debug_adjoint_mfma(int enable);
 int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
                     const int32_t* bl_j, int nbl, const double* z, const double* scale,
                     const double* add, double* out, void* workspace, size_t workspace_bytes,
