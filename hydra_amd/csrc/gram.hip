@@ -617,25 +617,34 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
   const int nc = (nantp + UCH - 1) / UCH;
   const int nphase = (ft_end > ft_begin) ? (ft_end - ft_begin) * nc : 0;
 
-  // LDS-DMA: one buffer = UCH rows x 224 columns = 70 pieces of 64 consecutive elements; a piece
-  // may straddle two rows (the per-lane SOURCE address makes that free); wave w issues pieces
-  // w, w+8, ...
+  // LDS-DMA: one buffer = UCH rows x K3_W columns = K3_PIECES pieces of 64 consecutive elements; a
+  // piece may straddle two rows (the per-lane SOURCE address makes that free); wave w issues pieces
+  // w, w + nwaves, ...  The per-lane source offsets inside a buffer (row r, source column sc) do
+  // not depend on the phase, so they are computed once: recomputing them per phase (a division by
+  // the row length and the tile-column selects, ~35 VALU instructions per piece, issued by both
+  // waves of a SIMD right after the barrier) kept the MFMA pipe idle for 16 % of the kernel.
+  // Rows beyond nantp in the last buffer read the scratch rows behind U (never multiplied).
+  constexpr int NPW = (K3_PIECES + 2 * K3_WC - 1) / (2 * K3_WC);   // pieces per wave
+  int off[NPW];
+#pragma unroll
+  for (int i = 0; i < NPW; ++i) {
+    int q = wave + 2 * K3_WC * i;
+    int L = q * 64 + lane;
+    int r = L / K3_W, col = L - r * K3_W;
+    int sc = (col < K3_TR) ? ti * K3_TR + col : tj * K3_TC + (col - K3_TR);
+    sc = min(sc, ns - 1);
+    off[i] = r * ns + sc;
+  }
   auto issue = [&](int p) {
     int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
-    const f64x2* src = U + ((size_t)ft * nantp) * ns;
+    const f64x2* src = U + ((size_t)ft * nantp + c * UCH) * ns;   // wave-uniform
+    f64x2* dst = s_u + (size_t)buf * UCH * K3_W + wave * 64;
 #pragma unroll
-    for (int i = 0; i < (K3_PIECES + 2 * K3_WC - 1) / (2 * K3_WC); ++i) {
-      int q = wave + 2 * K3_WC * i;
-      if (q < K3_PIECES) {
-        int L = q * 64 + lane;
-        int r = L / K3_W, col = L - r * K3_W;
-        int a = min(c * UCH + r, nantp - 1);
-        int sc = (col < K3_TR) ? ti * K3_TR + col : tj * K3_TC + (col - K3_TR);
-        sc = min(sc, ns - 1);
-        f64x2* dst = s_u + (size_t)buf * UCH * K3_W + q * 64;
+    for (int i = 0; i < NPW; ++i) {
+      if (wave + 2 * K3_WC * i < K3_PIECES) {
         __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + (size_t)a * ns + sc),
-            (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+            (const __attribute__((address_space(1))) void*)(src + off[i]),
+            (__attribute__((address_space(3))) void*)(dst + 2 * K3_WC * 64 * i), 16, 0, 0);
       }
     }
   };
@@ -949,7 +958,8 @@ size_t hydra_gram_uniform_workspace_bytes(int nf, int nt, int nant, int ns) {
   k3_plan((long long)nf * nt, ns, &ntiles, &nsplit, &per);
   size_t slabs = align_up((size_t)nsplit * ntiles * K3_TILE * sizeof(double), 256);
   int nantp = (nant + 1 + 3) / 4 * 4;   // room for the same-beam row
-  return slabs + (size_t)nf * nt * nantp * ns * 16;
+  // + UCH scratch rows: the staging of the last (partial) antenna buffer reads a whole buffer
+  return slabs + ((size_t)nf * nt * nantp + UCH) * ns * 16;
 }
 
 int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, double* w_ft,
