@@ -194,6 +194,123 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   }
 }
 
+// ---- R x in antenna space on the matrix cores -----------------------------------------------------
+// (R x)[b = (i,j)] = sum_s conj(V_i,s) V_j,s x_s = C[i][j],  C = conj(V) diag(x) V^T per (f,t): a
+// Hermitian (Nant x Nant) product with K = sources.  Both MFMA operands have the antenna on the
+// 16-lane axis and 4 consecutive sources on the k axis, so they are loaded straight from global
+// memory (64-byte pieces of 16 antenna rows per instruction; the next k-step uses the other half
+// of each 128-byte line) -- no LDS, no barrier.  One WAVE owns one (f,t) (or one of `nsplit` source
+// ranges of it when there are few (f,t)) and keeps all upper-triangular 16 x 16 blocks of C in
+// registers; C goes to a scratch array from which a gather kernel forms out[b] (any pair list,
+// repeated and reversed pairs included).  Nant <= 16 NR <= 64.
+template <int NR>
+__global__ void __launch_bounds__(256, NR <= 3 ? 2 : 1)
+apply_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
+                    const double* __restrict__ x, int nsplit, int k_per_split,
+                    f64x2* __restrict__ Cmat) {
+  constexpr int NP = NR * (NR + 1) / 2;
+  constexpr int NA = 16 * NR;
+  const int lane = threadIdx.x & 63;
+  const int kr = lane >> 4, lc = lane & 15;
+  const long long w = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (w >= (long long)nft * nsplit) return;
+  const int ft = (int)(w / nsplit), sp = (int)(w % nsplit);
+  // the waves of a workgroup share an (f,t) and take INTERLEAVED k-steps (wave sp: k-steps sp,
+  // sp + nsplit, ...), so that together they walk each antenna row front to back -- contiguous
+  // ranges per wave meant 4 x 48 scattered DRAM streams per workgroup and 2.1 TB/s
+  const int k0 = 0, k1 = k_per_split;
+  const f64x2* vft = V + (size_t)ft * nant * ns;
+  const f64x2* rowp[NR];
+#pragma unroll
+  for (int r = 0; r < NR; ++r) rowp[r] = vft + (size_t)min(r * 16 + lc, nant - 1) * ns;
+  f64x4 cx[NP], cy[NP];
+#pragma unroll
+  for (int p = 0; p < NP; ++p) {
+    cx[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    cy[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  constexpr int DEPTH = 4;   // k-steps of operands in flight
+  // Loads are unconditional (clamped, in-bounds addresses) and masked only through the weight xs
+  // of the A operand: a load under a condition is compiled into a branch with a wait right behind
+  // it, which serialised the whole stream (7.4 ms instead of 4.7).  Antenna rows beyond Nant repeat
+  // row Nant-1; their rows/columns of C are never gathered.
+  auto load = [&](int kk, f64x2 (&v)[NR], double& xs) {
+    int s = 4 * (kk * nsplit + sp) + kr;
+    int sc = min(s, ns - 1);
+#pragma unroll
+    for (int r = 0; r < NR; ++r) v[r] = rowp[r][sc];
+    double xv = x ? x[sc] : 1.0;
+    xs = (kk < k1 && s < ns) ? xv : 0.0;
+  };
+  f64x2 vb[DEPTH][NR];
+  double xb[DEPTH];
+#pragma unroll
+  for (int d = 0; d < DEPTH; ++d) load(k0 + d, vb[d], xb[d]);
+  for (int kk = k0; kk < k1; kk += DEPTH) {
+#pragma unroll
+    for (int d = 0; d < DEPTH; ++d) {
+      f64x2 v[NR];
+      double ax[NR], ay[NR];
+#pragma unroll
+      for (int r = 0; r < NR; ++r) {
+        v[r] = vb[d][r];
+        ax[r] = v[r].x * xb[d];
+        ay[r] = v[r].y * xb[d];
+      }
+      load(kk + d + DEPTH, vb[d], xb[d]);   // refill this slot (masked beyond k1)
+      // four sweeps over the block pairs, one product each: consecutive MFMAs never write the
+      // accumulator the previous one wrote
+#pragma unroll
+      for (int which = 0; which < 4; ++which) {
+        int p = 0;
+#pragma unroll
+        for (int rb = 0; rb < NR; ++rb)
+#pragma unroll
+          for (int cb = rb; cb < NR; ++cb, ++p) {
+            if (which == 0) cx[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].x, cx[p], 0, 0, 0);
+            if (which == 1) cy[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].y, cy[p], 0, 0, 0);
+            if (which == 2) cx[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay[rb], v[cb].y, cx[p], 0, 0, 0);
+            if (which == 3) cy[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ay[rb], v[cb].x, cy[p], 0, 0, 0);
+          }
+      }
+    }
+  }
+  f64x2* cm = Cmat + ((size_t)sp * nft + ft) * NA * NA;
+  int p = 0;
+#pragma unroll
+  for (int rb = 0; rb < NR; ++rb)
+#pragma unroll
+    for (int cb = rb; cb < NR; ++cb, ++p)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        cm[(size_t)(rb * 16 + kr + 4 * g) * NA + cb * 16 + lc] = f64x2{cx[p][g], cy[p][g]};
+}
+
+// out[b,ft] = rowmul[b,ft] * sum_split C[split][ft][i_b][j_b]; entries below the block diagonal
+// are the conjugates of the stored upper blocks
+__global__ void __launch_bounds__(256)
+apply_V_gather_kernel(const f64x2* __restrict__ Cmat, int nft, int na, int nsplit,
+                      const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
+                      const f64x2* __restrict__ rowmul, f64x2* __restrict__ out) {
+  size_t n = (size_t)nbl * nft;
+  for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n;
+       o += (size_t)gridDim.x * blockDim.x) {
+    int b = (int)(o / nft), ft = (int)(o % nft);
+    int i = bl_i[b], j = bl_j[b];
+    bool flip = (i >> 4) > (j >> 4);
+    int r = flip ? j : i, c = flip ? i : j;
+    f64x2 acc = {0.0, 0.0};
+    for (int sp = 0; sp < nsplit; ++sp) {
+      f64x2 v = Cmat[(((size_t)sp * nft + ft) * na + r) * na + c];
+      acc.x += v.x;
+      acc.y += v.y;
+    }
+    if (flip) acc.y = -acc.y;
+    if (rowmul) acc = cmul(rowmul[o], acc);
+    out[o] = acc;
+  }
+}
+
 // ---- R^H z in antenna space on the matrix cores -------------------------------------------------
 // sum_b Re(conj(conj(V_i) V_j) z_b) = Re sum_i V_i conj(W_i),  W = Zc V,  Zc[i][j] = sum of conj(z_b)
 // over the baselines b = (i, j): per (f,t) a (Nant x Nant) x (Nant x Ns) complex product instead of
@@ -247,8 +364,8 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   auto load_z = [&](int ft, f64x2 (&zr)[MAXB]) {
 #pragma unroll
     for (int q = 0; q < MAXB; ++q) {
-      int b = tid + 256 * q;
-      zr[q] = (b < nbl) ? zt[(size_t)ft * nbl + b] : f64x2{0.0, 0.0};
+      int b = min(tid + 256 * q, nbl - 1);   // unconditional, clamped: only stored where pos >= 0
+      zr[q] = zt[(size_t)ft * nbl + b];
     }
   };
   auto store_z = [&](int buf, const f64x2 (&zr)[MAXB]) {
@@ -272,12 +389,12 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     }
   };
   auto load_v = [&](int ft, f64x2 (&v)[NK]) {
-    const f64x2* vft = V + (size_t)ft * nant * ns;
+    // unconditional loads from clamped addresses (a conditional load compiles to a branch with a
+    // wait behind it): rows beyond Nant meet zero columns of Zc and give zero rows of W, lanes
+    // beyond Ns are never written out
+    const f64x2* vft = V + (size_t)ft * nant * ns + min(s, ns - 1);
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) {
-      int a = 4 * kk + kr;
-      v[kk] = (a < nant && s < ns) ? vft[(size_t)a * ns + s] : f64x2{0.0, 0.0};
-    }
+    for (int kk = 0; kk < NK; ++kk) v[kk] = vft[(size_t)min(4 * kk + kr, nant - 1) * ns];
   };
 
   double acc = 0.0;
@@ -513,13 +630,53 @@ static int launch_apply_V(const char* who, const double* V, int nf, int nt, int 
   return HYDRA_OK;
 }
 
+static void apply_V_mfma_plan(int nft, int ns, int* nsplit, int* k_per_split) {
+  int nk = (ns + 3) / 4;
+  int want = (nk >= 64) ? 4 : 1;            // the 4 waves of a workgroup share one (f,t)
+  while (want < 16 && (long long)nft * want < 4096 && nk / (2 * want) >= 16) want *= 2;
+  *nsplit = want;
+  *k_per_split = ((nk + want - 1) / want + 3) / 4 * 4;   // k-steps per wave, whole groups of 4
+}
+
+size_t hydra_apply_V_workspace_bytes(int nf, int nt, int nant, int ns) {
+  if (nf <= 0 || nt <= 0 || nant <= 0 || ns <= 0 || nant > 64) return 0;
+  int nsplit, kps;
+  apply_V_mfma_plan(nf * nt, ns, &nsplit, &kps);
+  size_t na = (size_t)(nant + 15) / 16 * 16;
+  return (size_t)nsplit * nf * nt * na * na * 16;
+}
+
 int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
                   const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
-                  double* out, void* stream) {
-  HYDRA_CHECK_ARG(V && bl_i && bl_j && x && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
+                  double* out, void* workspace, size_t workspace_bytes, void* stream) {
+  HYDRA_CHECK_ARG(V && bl_i && bl_j && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
                   "hydra_apply_V: bad arguments");
-  return launch_apply_V("hydra_apply_V", V, nf, nt, nant, ns, bl_i, bl_j, nbl, x, rowmul, out,
-                        nullptr, 1, stream);
+  size_t need = hydra_apply_V_workspace_bytes(nf, nt, nant, ns);
+  if (!workspace || need == 0 || !g_adjoint_mfma)   // pair-loop form (any Nant, no workspace)
+    return launch_apply_V("hydra_apply_V", V, nf, nt, nant, ns, bl_i, bl_j, nbl, x, rowmul, out,
+                          nullptr, 1, stream);
+  if (workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_apply_V: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int nft = nf * nt, nsplit, kps;
+  apply_V_mfma_plan(nft, ns, &nsplit, &kps);
+  int nr = (nant + 15) / 16;
+  long long nwaves = (long long)nft * nsplit;
+  unsigned grid = (unsigned)((nwaves + 3) / 4);
+  hipStream_t st = as_stream(stream);
+  const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
+  f64x2* cm = static_cast<f64x2*>(workspace);
+  if (nr == 1) apply_V_mfma_kernel<1><<<grid, 256, 0, st>>>(Vp, nft, nant, ns, x, nsplit, kps, cm);
+  else if (nr == 2) apply_V_mfma_kernel<2><<<grid, 256, 0, st>>>(Vp, nft, nant, ns, x, nsplit, kps, cm);
+  else if (nr == 3) apply_V_mfma_kernel<3><<<grid, 256, 0, st>>>(Vp, nft, nant, ns, x, nsplit, kps, cm);
+  else apply_V_mfma_kernel<4><<<grid, 256, 0, st>>>(Vp, nft, nant, ns, x, nsplit, kps, cm);
+  HYDRA_CHECK_LAUNCH("hydra_apply_V(mfma)");
+  size_t n = (size_t)nbl * nft;
+  apply_V_gather_kernel<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
+      cm, nft, nr * 16, nsplit, bl_i, bl_j, nbl, reinterpret_cast<const f64x2*>(rowmul),
+      reinterpret_cast<f64x2*>(out));
+  HYDRA_CHECK_LAUNCH("hydra_apply_V(gather)");
+  return HYDRA_OK;
 }
 
 int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,

@@ -100,10 +100,11 @@ class FactoredProj:
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
         out = _dev.empty((nbl, nf, nt), torch.complex128)
-        xd = _dev.f64(x)
+        xd = None if x is None else _dev.f64(x)          # None = a vector of ones
+        ws = _dev.workspace(_dev._lib.query("hydra_apply_V_workspace_bytes", nf, nt, nant, ns))
         _dev.call("hydra_apply_V", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(self.bl_i),
                   _dev.ptr(self.bl_j), nbl, _dev.ptr(xd), _dev.ptr(rowmul),
-                  _dev.ptr(out), _dev.stream_ptr())
+                  _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
         return out
 
     def adjoint(self, z, scale=None, add=None):
@@ -236,8 +237,7 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         _dev.call("hydra_row_factors", _dev.ptr(gains), _dev.ptr(w), _dev.ptr(bl_i),
                   _dev.ptr(bl_j), nbl, nf, nt, _dev.ptr(gg), _dev.ptr(None), st)
         A = _timed_gram(lambda: proj_chunk.gram(gains, w, prior_std=prior_here))
-        model = proj_chunk.apply(torch.ones(ns, dtype=torch.float64, device=data.device),
-                                 rowmul=gg)
+        model = proj_chunk.apply(None, rowmul=gg)        # R 1, ptsrc_sampler.py:104-106
     else:
         R = _dev.c128(proj_chunk).reshape(m, ns)
         rows = _dev.empty((nbl, nf, nt), torch.complex128)

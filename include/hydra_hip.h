@@ -220,11 +220,15 @@ int hydra_adjoint_R(const double* R, long long m, int ns, const double* z, const
                     void* stream);
 
 /* Factored forms of the two products above (operator given by V, never materialised):
- *   out[b,f,t] = gg[b,f,t] * sum_s conj(V[f,t,i_b,s]) V[f,t,j_b,s] x[s]
- *   out[s]     = scale[s] * sum_{b,f,t} Re( conj(conj(V_i) V_j) z[b,f,t] ) + add[s]       */
+ *   out[b,f,t] = gg[b,f,t] * sum_s conj(V[f,t,i_b,s]) V[f,t,j_b,s] x[s]     (x NULL = ones)
+ *   out[s]     = scale[s] * sum_{b,f,t} Re( conj(conj(V_i) V_j) z[b,f,t] ) + add[s]
+ * For Nant <= 64 both run in antenna space on the matrix cores (C = conj(V) diag(x) V^T and
+ * W = Zc V per (f,t)); hydra_apply_V then needs hydra_apply_V_workspace_bytes() of workspace
+ * (with workspace == NULL, or Nant > 64, it loops over the baselines instead).              */
+size_t hydra_apply_V_workspace_bytes(int nf, int nt, int nant, int ns);
 int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
                   const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
-                  double* out, void* stream);
+                  double* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns);
 /* Test hook: hydra_adjoint_V forms R^H z in antenna space on the matrix cores when Nant <= 64
  * (default) and with the pair-loop kernel otherwise; enable = 0 forces the pair loop.  Returns the

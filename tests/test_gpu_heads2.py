@@ -485,3 +485,57 @@ def test_antenna_space_adjoint_matches_pair_loop_and_numpy(hy, nant, ns, nf, nt,
             _dev._lib.query("hydra_debug_adjoint_mfma", prev)
     assert relerr(outs[0], ref) < 1e-12 and relerr(outs[1], ref) < 1e-12
     assert relerr(outs[0], outs[1]) < 1e-12
+
+
+@pytest.mark.parametrize("nant,ns,nf,nt,kind", [(5, 37, 2, 3, "all"), (17, 100, 3, 2, "all"),
+                                               (37, 250, 2, 5, "all"), (50, 70, 1, 3, "autos"),
+                                               (64, 130, 2, 2, "dups"), (33, 64, 40, 7, "flipped"),
+                                               (20, 1000, 1, 1, "all")])
+def test_antenna_space_apply_matches_pair_loop_and_numpy(hy, nant, ns, nf, nt, kind):
+    """hydra_apply_V on the matrix cores (C = conj(V) diag(x) V^T per (f,t) + gather) == the
+    pair-loop kernel == numpy; x given or NULL (= ones), with and without the row factors; few
+    (f,t) samples exercise the split over source ranges."""
+    import torch
+    from hydra_amd import _dev
+    rng = np.random.RandomState(nant + 1)
+    pairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    if kind == "autos":
+        pairs += [(i, i) for i in range(0, nant, 3)]
+    elif kind == "dups":
+        pairs += [pairs[k] for k in range(0, len(pairs), 17)] + [pairs[5], pairs[5]]
+    elif kind == "flipped":
+        pairs = [(j, i) if k % 3 == 0 else (i, j) for k, (i, j) in enumerate(pairs) if k % 2 == 0]
+    bl_i = np.array([p[0] for p in pairs], dtype=np.int32)
+    bl_j = np.array([p[1] for p in pairs], dtype=np.int32)
+    nbl = len(pairs)
+    V = rng.randn(nf, nt, nant, ns) + 1j * rng.randn(nf, nt, nant, ns)
+    x = rng.randn(ns)
+    rowmul = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    R = np.conj(V[:, :, bl_i, :]) * V[:, :, bl_j, :]                 # (nf, nt, nbl, ns)
+    Vd, bid, bjd = _dev.c128(V), _dev.i32(bl_i), _dev.i32(bl_j)
+    ws = _dev.workspace(_dev._lib.query("hydra_apply_V_workspace_bytes", nf, nt, nant, ns))
+    assert ws.numel() >= nf * nt * 16 * 16 * 16
+    for xv, rm in [(x, None), (None, rowmul), (x, rowmul)]:
+        ref = np.einsum("ftbs,s->bft", R, np.ones(ns) if xv is None else xv)
+        if rm is not None:
+            ref = ref * rm
+        xd = None if xv is None else _dev.f64(xv)
+        rd = None if rm is None else _dev.c128(rm)
+        outs = []
+        for enable in (1, 0):
+            prev = _dev._lib.query("hydra_debug_adjoint_mfma", enable)
+            try:
+                out = _dev.empty((nbl, nf, nt), torch.complex128)
+                _dev.call("hydra_apply_V", _dev.ptr(Vd), nf, nt, nant, ns, _dev.ptr(bid), _dev.ptr(bjd),
+                          nbl, _dev.ptr(xd), _dev.ptr(rd), _dev.ptr(out), _dev.ptr(ws), ws.numel(),
+                          _dev.stream_ptr())
+                outs.append(out.cpu().numpy())
+            finally:
+                _dev._lib.query("hydra_debug_adjoint_mfma", prev)
+        assert relerr(outs[0], ref) < 1e-12 and relerr(outs[1], ref) < 1e-12
+    # no workspace: the pair loop serves the call
+    out = _dev.empty((nbl, nf, nt), torch.complex128)
+    _dev.call("hydra_apply_V", _dev.ptr(Vd), nf, nt, nant, ns, _dev.ptr(bid), _dev.ptr(bjd), nbl,
+              _dev.ptr(_dev.f64(x)), _dev.ptr(None), _dev.ptr(out), _dev.ptr(None), 0,
+              _dev.stream_ptr())
+    assert relerr(out.cpu().numpy(), np.einsum("ftbs,s->bft", R, x)) < 1e-12
