@@ -140,9 +140,12 @@ gain_pairs_tiled_kernel(const f64x2* __restrict__ g, const double* __restrict__ 
 #pragma unroll
         for (int q = 0; q < 4; ++q) {
           int b = s_b[(wave * 4 + q) * 16 + ol + k];            // wave-uniform
-          double wv = (b >= 0) ? Wft[(size_t)b * nft] : 0.0;
-          if (a0 + q == o0 + ol + k) wv *= 2.0;
-          w[k][q] = wv;
+          // unconditional load (a load under a condition becomes a branch with a wait behind
+          // it and the 16 loads of a trip would go out one by one); absent pairs read baseline 0
+          // and are zeroed by the factor
+          double wv = Wft[(size_t)max(b, 0) * nft];
+          double fac = (b >= 0) ? ((a0 + q == o0 + ol + k) ? 2.0 : 1.0) : 0.0;
+          w[k][q] = wv * fac;
         }
 #pragma unroll
       for (int k = 0; k < 4; ++k) {
