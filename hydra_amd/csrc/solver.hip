@@ -751,8 +751,9 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
   hipStream_t s = as_stream(stream);
   // A p: half the matrix is read when the caller vouches for exact symmetry
   auto matvec = [&](const double* v, double* out) {
-    return symmetric ? hydra_symv_batched(A, n, 1, v, out, 0, sv_ws, sv_bytes, stream)
-                     : hydra_gemv(A, n, v, out, stream);
+    // below a few thousand unknowns the product is launch-bound and one launch beats two
+    return (symmetric && n >= 4096) ? hydra_symv_batched(A, n, 1, v, out, 0, sv_ws, sv_bytes, stream)
+                                    : hydra_gemv(A, n, v, out, stream);
   };
   int rc = matvec(x, ap);
   if (rc) return rc;
