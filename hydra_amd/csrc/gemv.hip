@@ -6,6 +6,7 @@
 // once = 16*Nf*Nt*Nant*Ns B.  All reductions run in a fixed order (no atomics) so results
 // are bitwise reproducible.
 #include <algorithm>
+#include <type_traits>
 
 #include "common.h"
 
@@ -319,17 +320,25 @@ apply_V_gather_kernel(const f64x2* __restrict__ Cmat, int nft, int na, int nspli
 // the voltages the lane already holds as MFMA B operands (the D-layout row 16 rb + kr + 4 g of a lane
 // is exactly the antenna of its B operand of k-step 4 rb + g).  Zc is scattered into LDS from the
 // transposed z, double buffered, one barrier per (f,t).  Nant <= 16 NR <= 64.
+#ifndef HYDRA_ADJ_OCC1_FROM
+#define HYDRA_ADJ_OCC1_FROM 4   // NR from which one workgroup per CU (512 registers a lane) is asked for
+#endif
+#ifndef HYDRA_ADJ_NOPF_FROM
+#define HYDRA_ADJ_NOPF_FROM 99  // NR from which the next sample's voltages are NOT prefetched into registers
+#endif
 template <int NR>
-__global__ void __launch_bounds__(256, 2)
+__global__ void __launch_bounds__(256, NR >= HYDRA_ADJ_OCC1_FROM ? 1 : 2)
 adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                       const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
                       const f64x2* __restrict__ zt, int ft_per_split, double* __restrict__ partial) {
   constexpr int NK = 4 * NR;            // k-steps of 4 antennas
   constexpr int S = 4 * NK + 1;         // LDS row stride of Zc (complex elements), odd
   constexpr int MAXB = (16 * NR * (16 * NR + 1) / 2 + 255) / 256;   // baselines per thread
+  constexpr bool PF = NR < HYDRA_ADJ_NOPF_FROM;
   extern __shared__ __align__(16) unsigned char smem[];
   f64x2* s_z = reinterpret_cast<f64x2*>(smem);                       // [2][16 NR][S]
   int* s_mask = reinterpret_cast<int*>(s_z + 2 * 16 * NR * S);       // [NR] bit kk set: block used
+  unsigned* s_off = reinterpret_cast<unsigned*>(s_mask + 4);         // [4][NK] byte offsets of V rows
   int* s_cnt = reinterpret_cast<int*>(s_z);   // [16 NR][16 NR] pair counts, prologue only (aliases Zc)
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int kr = lane >> 4, lc = lane & 15;
@@ -340,6 +349,10 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   // ---- prologue: zero both Zc buffers, note which blocks hold a baseline, look for duplicates
   for (int e = tid; e < 16 * NR * 16 * NR; e += 256) s_cnt[e] = 0;
   if (tid < NR) s_mask[tid] = 0;
+  // row offsets of the voltages a lane loads at k-step kk (rows beyond Nant clamped), kept in LDS
+  // and read back per sample: as loop invariants they would sit in 2 NK registers a lane
+  if (tid < 4 * NK)
+    s_off[tid] = (unsigned)min(4 * (tid % NK) + tid / NK, nant - 1) * (unsigned)ns * 16u;
   __syncthreads();
   int pos[MAXB];
   bool dup = false;
@@ -364,8 +377,8 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   auto load_z = [&](int ft, f64x2 (&zr)[MAXB]) {
 #pragma unroll
     for (int q = 0; q < MAXB; ++q) {
-      int b = min(tid + 256 * q, nbl - 1);   // unconditional, clamped: only stored where pos >= 0
-      zr[q] = zt[(size_t)ft * nbl + b];
+      unsigned b = (unsigned)min(tid + 256 * q, nbl - 1);   // unconditional, clamped: only stored where pos >= 0
+      zr[q] = *reinterpret_cast<const f64x2*>(reinterpret_cast<const char*>(zt + (size_t)ft * nbl) + b * 16u);
     }
   };
   auto store_z = [&](int buf, const f64x2 (&zr)[MAXB]) {
@@ -392,25 +405,37 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     // unconditional loads from clamped addresses (a conditional load compiles to a branch with a
     // wait behind it): rows beyond Nant meet zero columns of Zc and give zero rows of W, lanes
     // beyond Ns are never written out
-    const f64x2* vft = V + (size_t)ft * nant * ns + min(s, ns - 1);
+    const char* vft = reinterpret_cast<const char*>(V + (size_t)ft * nant * ns);   // uniform
+    const unsigned s16 = (unsigned)min(s, ns - 1) * 16u;
 #pragma unroll
-    for (int kk = 0; kk < NK; ++kk) v[kk] = vft[(size_t)min(4 * kk + kr, nant - 1) * ns];
+    for (int kk = 0; kk < NK; ++kk)
+      v[kk] = *reinterpret_cast<const f64x2*>(vft + (s_off[kr * NK + kk] + s16));
   };
 
+  // The block pattern is fixed before the (f,t) loop, and the loop exists twice, so that its body
+  // has no branch around the matrix instructions (a uniform branch per block makes the compiler
+  // copy every accumulator at every join): pair lists that leave all blocks below the block
+  // diagonal empty -- any i <= j list, the usual case -- skip those blocks; other lists take all.
+  bool upper = true;
+#pragma unroll
+  for (int rb = 0; rb < NR; ++rb) upper = upper && (mask[rb] & ((1 << (4 * rb)) - 1)) == 0;
+
   double acc = 0.0;
-  if (ft0 < ft1) {
-    f64x2 zr[MAXB], v[NK], vn[NK];
+  auto run = [&](auto upper_tag) {
+    constexpr bool UPPER = decltype(upper_tag)::value;
+    f64x2 zr[MAXB], v[NK], vn[PF ? NK : 1];
     load_z(ft0, zr);
     load_v(ft0, v);
     store_z(0, zr);
-    for (int ft = ft0; ft < ft1; ++ft) {
+    // one (f,t) sample: Zc[buf] x voltages vc; the next sample's z and voltages (into vnx) travel
+    // meanwhile.  "Next" is clamped to the last sample instead of tested, and the two register
+    // sets swap roles from call to call: a conditional copy vn -> v would cost a third set.
+    auto step = [&](int ft, f64x2 (&vc)[NK], f64x2 (&vnx)[PF ? NK : 1]) {
       const int buf = (ft - ft0) & 1;
+      const int nxt = min(ft + 1, ft1 - 1);
       __syncthreads();   // Zc[buf] is complete; nobody reads Zc[buf ^ 1] any more
-      const bool more = ft + 1 < ft1;
-      if (more) {        // next sample's z and voltages travel while this one is multiplied
-        load_z(ft + 1, zr);
-        load_v(ft + 1, vn);
-      }
+      load_z(nxt, zr);
+      if constexpr (PF) load_v(nxt, reinterpret_cast<f64x2 (&)[NK]>(vnx));
       const f64x2* zb = s_z + buf * 16 * NR * S;
       f64x4 wx[NR], wy[NR];
 #pragma unroll
@@ -418,30 +443,55 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
         wx[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
         wy[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
       }
+      // k-steps, the Zc operands of step kk + 1 read from LDS before the products of step kk are
+      // issued; the scheduling barriers keep the compiler from hoisting ALL the reads to the top
+      // (which costs more registers than there are)
+      f64x2 zc[NR], zn[NR];
+#pragma unroll
+      for (int rb = 0; rb < NR; ++rb) zc[rb] = zb[(rb * 16 + lc) * S + kr];
 #pragma unroll
       for (int kk = 0; kk < NK; ++kk) {
+        if (kk + 1 < NK) {
+#pragma unroll
+          for (int rb = 0; rb < NR; ++rb)
+            if (!(UPPER && kk + 1 < 4 * rb)) zn[rb] = zb[(rb * 16 + lc) * S + 4 * (kk + 1) + kr];
+        }
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) {
-          if (mask[rb] & (1 << kk)) {   // uniform over the workgroup
-            f64x2 zc = zb[(rb * 16 + lc) * S + 4 * kk + kr];
-            wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc.x, v[kk].x, wx[rb], 0, 0, 0);
-            wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-zc.y, v[kk].y, wx[rb], 0, 0, 0);
-            wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc.y, v[kk].x, wy[rb], 0, 0, 0);
-            wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc.x, v[kk].y, wy[rb], 0, 0, 0);
-          }
+          if (UPPER && kk < 4 * rb) continue;   // compile time
+          wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].x, wx[rb], 0, 0, 0);
+          wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-zc[rb].y, vc[kk].y, wx[rb], 0, 0, 0);
+          wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].y, vc[kk].x, wy[rb], 0, 0, 0);
+          wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].y, wy[rb], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+        if (kk + 1 < NK) {
+#pragma unroll
+          for (int rb = 0; rb < NR; ++rb)
+            if (!(UPPER && kk + 1 < 4 * rb)) zc[rb] = zn[rb];
         }
       }
 #pragma unroll
       for (int rb = 0; rb < NR; ++rb)
 #pragma unroll
         for (int g = 0; g < 4; ++g)
-          acc += wx[rb][g] * v[4 * rb + g].x + wy[rb][g] * v[4 * rb + g].y;
-      if (more) {
-        store_z(buf ^ 1, zr);
-#pragma unroll
-        for (int kk = 0; kk < NK; ++kk) v[kk] = vn[kk];
-      }
+          acc += wx[rb][g] * vc[4 * rb + g].x + wy[rb][g] * vc[4 * rb + g].y;
+      store_z(buf ^ 1, zr);   // (after the last sample: a copy of its own z, never read)
+      if constexpr (!PF) load_v(nxt, vc);
+    };
+    for (int ft = ft0; ft < ft1; ft += 2) {
+      step(ft, v, vn);
+      if (ft + 1 >= ft1) break;
+      if constexpr (PF)
+        step(ft + 1, reinterpret_cast<f64x2 (&)[NK]>(vn), reinterpret_cast<f64x2 (&)[PF ? NK : 1]>(v));
+      else
+        step(ft + 1, v, vn);
     }
+  };
+  if (ft0 < ft1) {
+    if (upper) run(std::true_type{});
+    else run(std::false_type{});
   }
   acc += __shfl_xor(acc, 16, 64);
   acc += __shfl_xor(acc, 32, 64);
@@ -731,12 +781,13 @@ int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int
   ctranspose_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const f64x2*>(z), nbl, nft, zt);
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V(transpose)");
   const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
-  if (nant <= 64 && g_adjoint_mfma) {   // antenna-space product on the matrix cores
+  // antenna-space product on the matrix cores (32-bit byte offsets within one (f,t) slice)
+  if (nant <= 64 && g_adjoint_mfma && (size_t)nant * ns * 16 < ((size_t)1 << 32)) {
     int nr = (nant + 15) / 16;
     dim3 grid((ns + 63) / 64, nsplit);
 #define HYDRA_ADJ_MFMA(NR_)                                                                      \
     {                                                                                            \
-      size_t lds = (size_t)2 * 16 * NR_ * (16 * NR_ + 1) * 16 + 16;                               \
+      size_t lds = (size_t)2 * 16 * NR_ * (16 * NR_ + 1) * 16 + 16 + 64 * NR_;                    \
       if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_mfma_kernel<NR_>), lds)) \
         return rc_lds;                                                                           \
       adjoint_V_mfma_kernel<NR_><<<grid, 256, lds, st>>>(Vp, nft, nant, ns, bl_i, bl_j, nbl, zt,   \

@@ -625,7 +625,7 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
   // waves of a SIMD right after the barrier) kept the MFMA pipe idle for 16 % of the kernel.
   // Rows beyond nantp in the last buffer read the scratch rows behind U (never multiplied).
   constexpr int NPW = (K3_PIECES + 2 * K3_WC - 1) / (2 * K3_WC);   // pieces per wave
-  int off[NPW];
+  unsigned off[NPW];   // byte offsets: 32 bits, added to a wave-uniform 64-bit base (saddr form)
 #pragma unroll
   for (int i = 0; i < NPW; ++i) {
     int q = wave + 2 * K3_WC * i;
@@ -633,11 +633,11 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
     int r = L / K3_W, col = L - r * K3_W;
     int sc = (col < K3_TR) ? ti * K3_TR + col : tj * K3_TC + (col - K3_TR);
     sc = min(sc, ns - 1);
-    off[i] = r * ns + sc;
+    off[i] = (unsigned)(r * ns + sc) * 16u;
   }
   auto issue = [&](int p) {
     int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
-    const f64x2* src = U + ((size_t)ft * nantp + c * UCH) * ns;   // wave-uniform
+    const char* src = reinterpret_cast<const char*>(U + ((size_t)ft * nantp + c * UCH) * ns);   // uniform
     f64x2* dst = s_u + (size_t)buf * UCH * K3_W + wave * 64;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
