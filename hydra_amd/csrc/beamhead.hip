@@ -17,93 +17,168 @@
 
 namespace hydra {
 
-constexpr int BH_TA = 64;   // antennas A per tile
-constexpr int BH_TQ = 64;   // basis columns q per tile
-constexpr int BH_KS = 16;   // sources per staged chunk
+constexpr int BH_TM = 64;    // antenna pairs (a, A) per tile
+constexpr int BH_TQ = 128;   // basis columns q per tile
+constexpr int BH_KS = 16;    // sources per staged chunk
 
-// grid (ft, rows * ceil(nant / 64), ceil(nq / 64)), 256 threads = 16 (A) x 16 (q), 4 x 4 outputs each.
+// The contraction per (f,t) is one complex GEMM  C[m,q] = sum_s P[s,m] B[s,q]  over the FLATTENED
+// pair index m = a Nant + A (the output (Nf,Nt,Nant,Nant,Q) is contiguous in m, and no tile is
+// padded from Nant up to a block multiple), K = sources.
+// One workgroup per (ft, 64-pair tile, 128-column tile), 512 threads = 8 waves = 2 (m) x 4 (q), wave tile 32 x 32.
+// Matrix cores, three real products per complex one:
+//   P1 = Px Bx,  P2 = Py By,  P3 = (Px + Py)(Bx + By):  Re = P1 - P2,  Im = P3 - P1 - P2
+// accumulated over all sources and combined once at the end (12 accumulator blocks, 48 VGPRs).
+// The pair products of a chunk of 16 sources are generated from global voltages into LDS by all
+// threads, B is copied beside them; the next chunk's global loads are issued before the matrix
+// loop of the current one and land in registers meanwhile (unconditional loads from clamped
+// addresses; out-of-range sources get P = 0, out-of-range pairs and columns are not stored).
 // row >= 0: only the antenna row `row` is formed and conjugated, i.e. the column
 //   C[f,t,A,row,q] = sum_s conj(V_A) V_row ref B  of the Hermitian pair matrix, written to an
-//   (Nf,Nt,Nant,Q) array -- all the sampled-antenna step needs (:458).
-__global__ void __launch_bounds__(256)
+//   (Nf,Nt,Nant,Q) array -- all the sampled-antenna step needs (:458); then M = Nant, m = A.
+__global__ void __launch_bounds__(512, 2)
 bess_contract_kernel(const f64x2* __restrict__ V, int nft, int nt, int nant, int ns,
                      const f64x2* __restrict__ B, int nq, const f64x2* __restrict__ ref, int row,
                      f64x2* __restrict__ out) {
-  __shared__ __align__(16) f64x2 sP[BH_KS][BH_TA + 1];
-  __shared__ __align__(16) f64x2 sB[BH_KS][BH_TQ];
-  const int ft = blockIdx.x, t = ft % nt;
-  const int ntile_a = (nant + BH_TA - 1) / BH_TA;
-  const int a = (row >= 0) ? row : (int)blockIdx.y / ntile_a;
-  const int A0 = ((int)blockIdx.y % ntile_a) * BH_TA;
-  const int q0 = blockIdx.z * BH_TQ;
-  const int tid = threadIdx.x, ty = tid >> 4, tx = tid & 15;
+  extern __shared__ __align__(16) unsigned char bh_smem[];
+  // rows of sP are padded by one element: the 16 lanes that write 16 sources of one pair would
+  // otherwise all hit the same banks
+  auto sP = reinterpret_cast<f64x2 (*)[BH_KS][BH_TM + 1]>(bh_smem);                                    // [2]
+  auto sB = reinterpret_cast<f64x2 (*)[BH_KS][BH_TQ]>(bh_smem + 2 * sizeof(f64x2[BH_KS][BH_TM + 1]));  // [2]
+  // 1-D grid of 8 * per blocks.  Hardware deals consecutive block ids round-robin to the 8 XCDs;
+  // id' = (id % 8) * per + id / 8 gives every XCD a contiguous range of tiles, pair tile fastest,
+  // then column tile, then (f,t): the 22 pair tiles that share one B tile and one voltage slice
+  // run together under one L2.
+  const int mtot = (row >= 0) ? nant : nant * nant;
+  const int nmt = (mtot + BH_TM - 1) / BH_TM, nqt = (nq + BH_TQ - 1) / BH_TQ;
+  const long long per = gridDim.x / 8;
+  const long long tile = (long long)(blockIdx.x % 8) * per + blockIdx.x / 8;
+  if (tile >= (long long)nft * nmt * nqt) return;
+  const int ft = (int)(tile / ((long long)nmt * nqt)), t = ft % nt;
+  const int m0 = (int)(tile % nmt) * BH_TM, q0 = (int)((tile / nmt) % nqt) * BH_TQ;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave & 1, wq = wave >> 1;
+  const int kr = lane >> 4, lc = lane & 15;
   const f64x2* vft = V + (size_t)ft * nant * ns;
-  const f64x2* va = vft + (size_t)a * ns;
   const f64x2* bt = B + (size_t)t * ns * nq;
   const f64x2* rf = ref ? ref + (size_t)ft * ns : nullptr;
-  f64x2 acc[4][4];
-#pragma unroll
-  for (int i = 0; i < 4; ++i)
-#pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = f64x2{0.0, 0.0};
 
-  for (int s0 = 0; s0 < ns; s0 += BH_KS) {
-    __syncthreads();
-    // pair products of this chunk: consecutive threads <-> consecutive sources of one antenna
+  // staging roles.  P: element (ks, ml0 + 32 u), u < 2 -- 16 consecutive threads <-> 16 consecutive
+  // sources of one pair.  B: element (kb0 + 4 u, ql), u < 4 -- consecutive threads <-> columns.
+  const int ks = tid & 15, ml0 = tid >> 4;
+  const int ql = tid & 127, kb0 = tid >> 7;
+  int offa[2], offA[2];      // row offsets of V_a and V_A (elements)
+  int kind[2];               // pair (i, j): 0 auto, +1 above the diagonal, -1 below
+  bool mval[2];
 #pragma unroll
-    for (int e = tid; e < BH_KS * BH_TA; e += 256) {
-      int ks = e % BH_KS, Al = e / BH_KS;
-      int s = s0 + ks, A = A0 + Al;
-      f64x2 p = {0.0, 0.0};
-      if (s < ns && A < nant) {
-        f64x2 x = va[s], y = vft[(size_t)A * ns + s];
-        p = cmul_conj(x, y);                       // conj(V_a) V_A = entry (a, A)
-        if (row >= 0) p.y = -p.y;                  // entry (A, row) of the Hermitian matrix
-        // the reference scales the upper-triangular cube by ref and THEN adds the conjugate
-        // transpose (:410-413): entries above the diagonal carry ref, those below conj(ref),
-        // the autos appear twice (with Re ref)
-        const int i = (row >= 0) ? A : a, j = (row >= 0) ? a : A;
-        f64x2 r = rf ? rf[s] : f64x2{1.0, 0.0};
-        if (i > j) r.y = -r.y;
-        p = (i == j) ? f64x2{2.0 * p.x * r.x, 0.0} : cmul(p, r);
+  for (int u = 0; u < 2; ++u) {
+    int m = m0 + ml0 + 32 * u;
+    mval[u] = m < mtot;
+    m = min(m, mtot - 1);
+    int a = (row >= 0) ? row : m / nant;
+    int A = (row >= 0) ? m : m - a * nant;
+    offa[u] = a * ns;
+    offA[u] = A * ns;
+    // entry (i, j) = (a, A), or (A, row) in column mode
+    const int i = (row >= 0) ? A : a, j = (row >= 0) ? a : A;
+    kind[u] = (i == j) ? 0 : (i > j ? -1 : 1);
+  }
+  const int qcl = min(q0 + ql, nq - 1);
+
+  f64x2 gx[2], gy[2], gr, gb[4];
+  auto fetch = [&](int s0) {
+    const int s = min(s0 + ks, ns - 1);
+    gr = rf ? rf[s] : f64x2{1.0, 0.0};
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      gx[u] = vft[offa[u] + s];
+      gy[u] = vft[offA[u] + s];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u)
+      gb[u] = bt[(size_t)min(s0 + kb0 + 4 * u, ns - 1) * nq + qcl];
+  };
+  auto stash = [&](int s0, int buf) {
+    const bool sval = s0 + ks < ns;
+#pragma unroll
+    for (int u = 0; u < 2; ++u) {
+      f64x2 p = cmul_conj(gx[u], gy[u]);             // conj(V_a) V_A = entry (a, A)
+      if (row >= 0) p.y = -p.y;                      // entry (A, row) of the Hermitian matrix
+      // the reference scales the upper-triangular cube by ref and THEN adds the conjugate transpose
+      // (:410-413): entries above the diagonal carry ref, those below conj(ref), the autos appear
+      // twice (with Re ref)
+      const f64x2 r = {gr.x, gr.y * (double)kind[u]};
+      p = (kind[u] == 0) ? f64x2{2.0 * p.x * r.x, 0.0} : cmul(p, r);
+      sP[buf][ks][ml0 + 32 * u] = (sval && mval[u]) ? p : f64x2{0.0, 0.0};
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) sB[buf][kb0 + 4 * u][ql] = gb[u];   // finite everywhere; P = 0 masks s >= ns
+  };
+
+  f64x4 acc1[2][2], acc2[2][2], acc3[2][2];
+#pragma unroll
+  for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      acc1[mb][qb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      acc2[mb][qb] = f64x4{0.0, 0.0, 0.0, 0.0};
+      acc3[mb][qb] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+
+  auto products = [&](int buf, int kk) {
+    f64x2 pa[2], pb[2];
+    double psum[2], bsum[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+      pa[mb] = sP[buf][4 * kk + kr][(2 * wm + mb) * 16 + lc];
+      psum[mb] = pa[mb].x + pa[mb].y;
+    }
+#pragma unroll
+    for (int qb = 0; qb < 2; ++qb) {
+      pb[qb] = sB[buf][4 * kk + kr][(2 * wq + qb) * 16 + lc];
+      bsum[qb] = pb[qb].x + pb[qb].y;
+    }
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        acc1[mb][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[mb].x, pb[qb].x, acc1[mb][qb], 0, 0, 0);
+        acc2[mb][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(pa[mb].y, pb[qb].y, acc2[mb][qb], 0, 0, 0);
+        acc3[mb][qb] = __builtin_amdgcn_mfma_f64_16x16x4f64(psum[mb], bsum[qb], acc3[mb][qb], 0, 0, 0);
       }
-      sP[ks][Al] = p;
+  };
+
+  // two LDS buffers, one barrier per chunk: chunk c + 1 is written (from the registers fetched
+  // during chunk c - 1) in the middle of chunk c's products, chunk c + 2's loads follow it
+  fetch(0);
+  stash(0, 0);
+  if (BH_KS < ns) fetch(BH_KS);
+  int buf = 0;
+  for (int s0 = 0; s0 < ns; s0 += BH_KS, buf ^= 1) {
+    __syncthreads();   // buffer `buf` is complete; nobody reads the other one any more
+#pragma unroll
+    for (int kk = 0; kk < BH_KS / 8; ++kk) products(buf, kk);
+    if (s0 + BH_KS < ns) {
+      stash(s0 + BH_KS, buf ^ 1);
+      if (s0 + 2 * BH_KS < ns) fetch(s0 + 2 * BH_KS);
     }
 #pragma unroll
-    for (int e = tid; e < BH_KS * BH_TQ; e += 256) {
-      int ql = e % BH_TQ, ks = e / BH_TQ;
-      int s = s0 + ks, q = q0 + ql;
-      sB[ks][ql] = (s < ns && q < nq) ? bt[(size_t)s * nq + q] : f64x2{0.0, 0.0};
-    }
-    __syncthreads();
-#pragma unroll 4
-    for (int ks = 0; ks < BH_KS; ++ks) {
-      f64x2 p[4], b[4];
-#pragma unroll
-      for (int i = 0; i < 4; ++i) p[i] = sP[ks][ty + 16 * i];
-#pragma unroll
-      for (int j = 0; j < 4; ++j) b[j] = sB[ks][tx + 16 * j];
-#pragma unroll
-      for (int i = 0; i < 4; ++i)
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-          acc[i][j].x += p[i].x * b[j].x - p[i].y * b[j].y;
-          acc[i][j].y += p[i].x * b[j].y + p[i].y * b[j].x;
-        }
-    }
+    for (int kk = BH_KS / 8; kk < BH_KS / 4; ++kk) products(buf, kk);
   }
+  // D layout: lane holds rows kr + 4 g, column lc of each 16 x 16 block
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
-    int A = A0 + ty + 16 * i;
-    if (A >= nant) continue;
-    size_t base = (row >= 0) ? ((size_t)ft * nant + A) * nq
-                             : (((size_t)ft * nant + a) * nant + A) * nq;
+  for (int mb = 0; mb < 2; ++mb)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      int q = q0 + tx + 16 * j;
-      if (q < nq) out[base + q] = acc[i][j];
+    for (int g = 0; g < 4; ++g) {
+      const int m = m0 + (2 * wm + mb) * 16 + kr + 4 * g;
+      if (m >= mtot) continue;
+      f64x2* o = out + ((size_t)ft * mtot + m) * nq;
+#pragma unroll
+      for (int qb = 0; qb < 2; ++qb) {
+        const int q = q0 + (2 * wq + qb) * 16 + lc;
+        const double p1 = acc1[mb][qb][g], p2 = acc2[mb][qb][g], p3 = acc3[mb][qb][g];
+        if (q < nq) o[q] = f64x2{p1 - p2, p3 - p1 - p2};
+      }
     }
-  }
 }
 
 // out[f,t,k,B] = sum_b conj(coef[b,f,A_k]) C[f,t,A_k,(samp,) b,B],  A_k = k-th antenna != samp
@@ -156,11 +231,17 @@ int hydra_bess_sky_contraction(const double* V, int nf, int nt, int nant, int ns
                   "hydra_bess_sky_contraction: bad arguments");
   HYDRA_CHECK_ARG(row < nant, "hydra_bess_sky_contraction: row %d out of range (Nant = %d)", row,
                   nant);
-  int ntile_a = (nant + BH_TA - 1) / BH_TA, ntile_q = (nq + BH_TQ - 1) / BH_TQ;
-  long long gy = (long long)(row >= 0 ? 1 : nant) * ntile_a;
-  HYDRA_CHECK_ARG(gy <= 65535 && ntile_q <= 65535, "hydra_bess_sky_contraction: grid too large");
-  dim3 grid(nf * nt, (unsigned)gy, ntile_q);
-  bess_contract_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+  HYDRA_CHECK_ARG((long long)nant * ns < 2147483647LL && (long long)nant * nant < 2147483647LL,
+                  "hydra_bess_sky_contraction: (antenna, source) slice too large for 32-bit offsets");
+  const int mtot = row >= 0 ? nant : nant * nant;
+  long long ntile_q = (nq + BH_TQ - 1) / BH_TQ;
+  long long ntile_m = ((long long)mtot + BH_TM - 1) / BH_TM;
+  long long tiles = (long long)nf * nt * ntile_m * ntile_q;
+  HYDRA_CHECK_ARG(tiles < 2147483647LL - 8, "hydra_bess_sky_contraction: grid too large");
+  unsigned grid = (unsigned)((tiles + 7) / 8 * 8);
+  constexpr size_t lds = 2 * (sizeof(f64x2[BH_KS][BH_TM + 1]) + sizeof(f64x2[BH_KS][BH_TQ]));   // 96.5 KiB
+  if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&bess_contract_kernel), lds)) return rc_lds;
+  bess_contract_kernel<<<grid, 512, lds, as_stream(stream)>>>(
       reinterpret_cast<const f64x2*>(V), nf * nt, nt, nant, ns, reinterpret_cast<const f64x2*>(B), nq,
       reinterpret_cast<const f64x2*>(ref), row, reinterpret_cast<f64x2*>(out));
   HYDRA_CHECK_LAUNCH("hydra_bess_sky_contraction");
