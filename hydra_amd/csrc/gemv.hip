@@ -127,7 +127,9 @@ scale_rows_kernel(const f64x2* y, const double* __restrict__ w, long long m, f64
 // so that different antennas land on different banks.
 
 // out[b,ft] = rowmul[b,ft] * sum_s conj(V[ft,i_b,s]) V[ft,j_b,s] x[s]
-// One workgroup per (f,t): voltages staged 64 sources at a time, thread <-> baseline.
+// One workgroup per (f,t) and baseline chunk (blockIdx.z: chunks of 2048 baselines, dealt round
+// robin -- only when there are too few (f,t) to fill the chip, since every chunk restages the
+// voltages): voltages staged 64 sources at a time, thread <-> baseline.
 // With seg != NULL (region sums): blockIdx.y = region r, the sum runs over the sources
 // seg[r] <= s < seg[r+1] only and lands in out[(b,ft), r]; x may be NULL (= 1).
 template <int VCH>
@@ -148,7 +150,7 @@ apply_V_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   const int s_lo = seg ? seg[blockIdx.y] : 0, s_hi = seg ? seg[blockIdx.y + 1] : ns;
   // up to 8 baselines per thread are accumulated in registers per pass over the sources
   constexpr int MAXB = 8;
-  for (int bbase = 0; bbase < nbl; bbase += 256 * MAXB) {
+  for (int bbase = blockIdx.z * 256 * MAXB; bbase < nbl; bbase += gridDim.z * 256 * MAXB) {
     f64x2 acc[MAXB];
     int bi[MAXB], bj[MAXB];
 #pragma unroll
@@ -664,7 +666,11 @@ static int launch_apply_V(const char* who, const double* V, int nf, int nt, int 
   const f64x2* rm = reinterpret_cast<const f64x2*>(rowmul);
   f64x2* op = reinterpret_cast<f64x2*>(out);
   size_t lds64 = ((size_t)nant * 65) * 16 + 64 * 8, lds16 = ((size_t)nant * 17) * 16 + 16 * 8;
-  dim3 grid(nf * nt, seg ? nreg : 1);
+  // few (f,t) (config 5: 2 per step, 61 075 baselines): spread the baseline chunks over the chip
+  const long long base_wgs = (long long)nf * nt * (seg ? nreg : 1);
+  const long long chunks = ((long long)nbl + 2047) / 2048;
+  const unsigned nz = (unsigned)std::max<long long>(1, std::min<long long>({chunks, 1024 / base_wgs, 65535}));
+  dim3 grid(nf * nt, seg ? nreg : 1, nz);
   if (lds64 <= 160 * 1024) {
     if (int rc_lds = reserve_lds(reinterpret_cast<const void*>(&apply_V_kernel<64>), lds64)) return rc_lds;
     apply_V_kernel<64><<<grid, 256, lds64, as_stream(stream)>>>(Vp, nf * nt, nant, ns, bl_i, bl_j,

@@ -307,7 +307,8 @@ def test_cg_long_vector_step_matches_oracle(hy, use_norm_tol):
     assert np.abs(A @ x2 - b2).max() < 10 * tol
 
 
-@pytest.mark.parametrize("n,nb", [(64, 1), (1, 2), (130, 3), (257, 2), (1000, 1)])
+@pytest.mark.parametrize("n,nb", [(64, 1), (1, 2), (130, 3), (257, 2), (1000, 1), (1100, 2), (2049, 1),
+                                  (4160, 1)])
 def test_symmetric_half_read_matvec_matches_numpy(hy, n, nb):
     """hydra_symv_batched (reads the lower blocks only) == A @ x for symmetric A; plain and
     accumulating; odd n takes the 8-byte-load variant."""
@@ -447,7 +448,8 @@ def test_polybeam_generator_matches_oracle(hy):
 
 @pytest.mark.parametrize("nant,ns,nf,nt,kind", [(5, 37, 2, 3, "all"), (17, 100, 3, 2, "all"),
                                                (37, 250, 2, 5, "all"), (50, 70, 1, 3, "autos"),
-                                               (64, 130, 2, 2, "dups"), (33, 64, 40, 7, "sparse")])
+                                               (64, 130, 2, 2, "dups"), (33, 64, 40, 7, "sparse"),
+                                               (41, 90, 3, 3, "flipped"), (60, 50, 1, 5, "flipped")])
 def test_antenna_space_adjoint_matches_pair_loop_and_numpy(hy, nant, ns, nf, nt, kind):
     """hydra_adjoint_V on the matrix cores (W = Zc V per (f,t)) == the pair-loop kernel == numpy,
     for complete arrays, lists with autos, repeated pairs, and sparse lists."""
@@ -461,6 +463,8 @@ def test_antenna_space_adjoint_matches_pair_loop_and_numpy(hy, nant, ns, nf, nt,
         pairs += [pairs[k] for k in range(0, len(pairs), 17)] + [pairs[5], pairs[5]]
     elif kind == "sparse":
         pairs = [p for k, p in enumerate(pairs) if k % 5 == 1]
+    elif kind == "flipped":   # pairs below the block diagonal: the kernel's all-blocks loop
+        pairs = [(j, i) if k % 3 == 0 else (i, j) for k, (i, j) in enumerate(pairs)]
     bl_i = np.array([p[0] for p in pairs], dtype=np.int32)
     bl_j = np.array([p[1] for p in pairs], dtype=np.int32)
     nbl = len(pairs)
