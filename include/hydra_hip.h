@@ -164,7 +164,8 @@ int hydra_gram(const double* R, const double* rows, long long m, int ns, const d
 int hydra_prior_epilogue(double* G, int ns, const double* prior_std, const double* add_diag,
                          void* stream);
 
-/* Same Gram without materialising R (R would be 273 GB at BASELINE config 2):
+/* Same Gram without materialising R (R would be 273 GB at BASELINE config 2), i.e.
+ * ptsrc_sampler.py:48-94 on the output of vis_simulator.py:281-289 / ptsrc_sampler.py:209-213:
  *   R'[(b,f,t),s] = g_i conj(g_j) sqrt(w_bft) conj(V[f,t,i_b,s]) V[f,t,j_b,s].
  * gains (Nant,Nf,Nt) c128 or NULL; inv_noise (Nbl,Nf,Nt) f64 or NULL.
  * Tables (built by hydra_amd/_tables.py) group the baselines by antenna block so that one
@@ -219,7 +220,8 @@ int hydra_adjoint_R(const double* R, long long m, int ns, const double* z, const
                     const double* add, double* out, void* workspace, size_t workspace_bytes,
                     void* stream);
 
-/* Factored forms of the two products above (operator given by V, never materialised):
+/* Factored forms of the two products above (operator given by V, never materialised;
+ * ptsrc_sampler.py:104-106,124,138; example.py:974-976):
  *   out[b,f,t] = gg[b,f,t] * sum_s conj(V[f,t,i_b,s]) V[f,t,j_b,s] x[s]     (x NULL = ones)
  *   out[s]     = scale[s] * sum_{b,f,t} Re( conj(conj(V_i) V_j) z[b,f,t] ) + add[s]
  * For Nant <= 64 both run in antenna space on the matrix cores (C = conj(V) diag(x) V^T and
@@ -230,14 +232,14 @@ int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32
                   const int32_t* bl_j, int nbl, const double* x, const double* rowmul,
                   double* out, void* workspace, size_t workspace_bytes, void* stream);
 size_t hydra_adjoint_V_workspace_bytes(int nf, int nt, int nbl, int ns);
-/* Test hook: hydra_adjoint_V forms R^H z in antenna space on the matrix cores when Nant <= 64
- * (default) and with the pair-loop kernel otherwise; enable = 0 forces the pair loop.  Returns the
- * previous setting.  No counterpart in the reference.                                        */
-int hydra_debug_adjoint_mfma(int enable);
 int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
                     const int32_t* bl_j, int nbl, const double* z, const double* scale,
                     const double* add, double* out, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* Test hook: hydra_adjoint_V forms R^H z in antenna space on the matrix cores when Nant <= 64
+ * (default) and with the pair-loop kernel otherwise; enable = 0 forces the pair loop.  Returns the
+ * previous setting.  No counterpart in the reference.                                        */
+int hydra_debug_adjoint_mfma(int enable);
 
 /* GCR right-hand-side row term:
  *   z[r] = conj(gg[r]) * ( (data[r] - model[r]) * w[r] + omega_n[r] * sqrt(w[r]) )
@@ -368,8 +370,8 @@ int hydra_gain_pairs(const double* g, int nvec, int nant, int nft, const double*
                      const int32_t* adj_ptr_host, const int32_t* adj_ptr, const int32_t* adj_b,
                      const int32_t* adj_o, int nadj, double* y, void* stream);
 
-/* Same operator for pair lists without duplicates, tiled through LDS (16 antennas x 64 (f,t)
- * per workgroup; see csrc/gain.hip): pairb (Nant,Nant) int32 = baseline index of the unordered
+/* Same operator (gain_sampler.py:278-284) for pair lists without duplicates, tiled through LDS
+ * (16 antennas x 64 (f,t) per workgroup; see csrc/gain.hip): pairb (Nant,Nant) int32 = baseline index of the unordered
  * pair {a,o} (symmetric), -1 if absent; an auto-correlation counts twice.                   */
 int hydra_gain_pairs_tiled(const double* g, int nvec, int nant, int nft, const double* W, int nbl,
                            const int32_t* pairb, double* y, void* stream);
