@@ -226,11 +226,17 @@ apply_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
   const f64x2* rowp[NR];
 #pragma unroll
   for (int r = 0; r < NR; ++r) rowp[r] = vft + (size_t)min(r * 16 + lc, nant - 1) * ns;
-  f64x4 cx[NP], cy[NP];
+  // three real products per complex one: with a = conj(v_i) x = (ax, -ay), b = v_j = (bx, by)
+  //   P1 = ax bx,  P2 = ay by,  P3 = (ax - ay)(bx + by):   Re C = P1 + P2,  Im C = P3 - P1 + P2
+  // (NR = 4 keeps the four-product form, p1 = Re C, p2 = Im C: a third accumulator set would not
+  // fit its 256 architectural registers)
+  constexpr bool THREE = NR <= 3;
+  f64x4 p1[NP], p2[NP], p3[THREE ? NP : 1];
 #pragma unroll
   for (int p = 0; p < NP; ++p) {
-    cx[p] = f64x4{0.0, 0.0, 0.0, 0.0};
-    cy[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    p1[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    p2[p] = f64x4{0.0, 0.0, 0.0, 0.0};
+    if (THREE) p3[p] = f64x4{0.0, 0.0, 0.0, 0.0};
   }
   constexpr int DEPTH = 4;   // k-steps of operands in flight
   // Loads are unconditional (clamped, in-bounds addresses) and masked only through the weight xs
@@ -253,27 +259,37 @@ apply_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 #pragma unroll
     for (int d = 0; d < DEPTH; ++d) {
       f64x2 v[NR];
-      double ax[NR], ay[NR];
+      double ax[NR], ay[NR], ad[NR], bs[NR];
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         v[r] = vb[d][r];
         ax[r] = v[r].x * xb[d];
         ay[r] = v[r].y * xb[d];
+        if (THREE) {
+          ad[r] = ax[r] - ay[r];
+          bs[r] = v[r].x + v[r].y;
+        }
       }
       load(kk + d + DEPTH, vb[d], xb[d]);   // refill this slot (masked beyond k1)
-      // four sweeps over the block pairs, one product each: consecutive MFMAs never write the
+      // three sweeps over the block pairs, one product each: consecutive MFMAs never write the
       // accumulator the previous one wrote
 #pragma unroll
-      for (int which = 0; which < 4; ++which) {
+      for (int which = 0; which < (THREE ? 3 : 4); ++which) {
         int p = 0;
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb)
 #pragma unroll
           for (int cb = rb; cb < NR; ++cb, ++p) {
-            if (which == 0) cx[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].x, cx[p], 0, 0, 0);
-            if (which == 1) cy[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].y, cy[p], 0, 0, 0);
-            if (which == 2) cx[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay[rb], v[cb].y, cx[p], 0, 0, 0);
-            if (which == 3) cy[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ay[rb], v[cb].x, cy[p], 0, 0, 0);
+            if constexpr (THREE) {
+              if (which == 0) p1[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].x, p1[p], 0, 0, 0);
+              if (which == 1) p2[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay[rb], v[cb].y, p2[p], 0, 0, 0);
+              if (which == 2) p3[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ad[rb], bs[cb], p3[p], 0, 0, 0);
+            } else {
+              if (which == 0) p1[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].x, p1[p], 0, 0, 0);
+              if (which == 1) p2[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax[rb], v[cb].y, p2[p], 0, 0, 0);
+              if (which == 2) p1[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay[rb], v[cb].y, p1[p], 0, 0, 0);
+              if (which == 3) p2[p] = __builtin_amdgcn_mfma_f64_16x16x4f64(-ay[rb], v[cb].x, p2[p], 0, 0, 0);
+            }
           }
       }
     }
@@ -286,7 +302,9 @@ apply_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
     for (int cb = rb; cb < NR; ++cb, ++p)
 #pragma unroll
       for (int g = 0; g < 4; ++g)
-        cm[(size_t)(rb * 16 + kr + 4 * g) * NA + cb * 16 + lc] = f64x2{cx[p][g], cy[p][g]};
+        cm[(size_t)(rb * 16 + kr + 4 * g) * NA + cb * 16 + lc] =
+            THREE ? f64x2{p1[p][g] + p2[p][g], p3[THREE ? p : 0][g] - p1[p][g] + p2[p][g]}
+                  : f64x2{p1[p][g], p2[p][g]};
 }
 
 // out[b,ft] = rowmul[b,ft] * sum_split C[split][ft][i_b][j_b]; entries below the block diagonal
@@ -324,6 +342,9 @@ apply_V_gather_kernel(const f64x2* __restrict__ Cmat, int nft, int na, int nspli
 // transposed z, double buffered, one barrier per (f,t).  Nant <= 16 NR <= 64.
 #ifndef HYDRA_ADJ_OCC1_FROM
 #define HYDRA_ADJ_OCC1_FROM 4   // NR from which one workgroup per CU (512 registers a lane) is asked for
+#endif
+#ifndef HYDRA_ADJ_THREE_MAX
+#define HYDRA_ADJ_THREE_MAX 4   // largest NR that uses the 3-product complex multiply
 #endif
 #ifndef HYDRA_ADJ_NOPF_FROM
 #define HYDRA_ADJ_NOPF_FROM 99  // NR from which the next sample's voltages are NOT prefetched into registers
@@ -439,11 +460,15 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
       load_z(nxt, zr);
       if constexpr (PF) load_v(nxt, reinterpret_cast<f64x2 (&)[NK]>(vnx));
       const f64x2* zb = s_z + buf * 16 * NR * S;
-      f64x4 wx[NR], wy[NR];
+      // W = Zc V with three real products per complex one:
+      //   P1 = Zr Vr,  P2 = Zi Vi,  P3 = (Zr + Zi)(Vr + Vi):  Re W = P1 - P2,  Im W = P3 - P1 - P2
+      constexpr bool THREE = NR <= HYDRA_ADJ_THREE_MAX;
+      f64x4 w1[NR], w2[NR], w3[THREE ? NR : 1];
 #pragma unroll
       for (int rb = 0; rb < NR; ++rb) {
-        wx[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
-        wy[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        w1[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        w2[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
+        if (THREE) w3[rb] = f64x4{0.0, 0.0, 0.0, 0.0};
       }
       // k-steps, the Zc operands of step kk + 1 read from LDS before the products of step kk are
       // issued; the scheduling barriers keep the compiler from hoisting ALL the reads to the top
@@ -459,13 +484,20 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
             if (!(UPPER && kk + 1 < 4 * rb)) zn[rb] = zb[(rb * 16 + lc) * S + 4 * (kk + 1) + kr];
         }
         __builtin_amdgcn_sched_barrier(0);
+        const double vs = vc[kk].x + vc[kk].y;
 #pragma unroll
         for (int rb = 0; rb < NR; ++rb) {
           if (UPPER && kk < 4 * rb) continue;   // compile time
-          wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].x, wx[rb], 0, 0, 0);
-          wx[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-zc[rb].y, vc[kk].y, wx[rb], 0, 0, 0);
-          wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].y, vc[kk].x, wy[rb], 0, 0, 0);
-          wy[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].y, wy[rb], 0, 0, 0);
+          if constexpr (THREE) {
+            w1[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].x, w1[rb], 0, 0, 0);
+            w2[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].y, vc[kk].y, w2[rb], 0, 0, 0);
+            w3[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x + zc[rb].y, vs, w3[rb], 0, 0, 0);
+          } else {
+            w1[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].x, w1[rb], 0, 0, 0);
+            w1[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(-zc[rb].y, vc[kk].y, w1[rb], 0, 0, 0);
+            w2[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].y, vc[kk].x, w2[rb], 0, 0, 0);
+            w2[rb] = __builtin_amdgcn_mfma_f64_16x16x4f64(zc[rb].x, vc[kk].y, w2[rb], 0, 0, 0);
+          }
         }
         __builtin_amdgcn_sched_barrier(0);
         if (kk + 1 < NK) {
@@ -477,8 +509,11 @@ adjoint_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 #pragma unroll
       for (int rb = 0; rb < NR; ++rb)
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          acc += wx[rb][g] * vc[4 * rb + g].x + wy[rb][g] * vc[4 * rb + g].y;
+        for (int g = 0; g < 4; ++g) {
+          const double wre = THREE ? w1[rb][g] - w2[rb][g] : w1[rb][g];
+          const double wim = THREE ? w3[THREE ? rb : 0][g] - w1[rb][g] - w2[rb][g] : w2[rb][g];
+          acc += wre * vc[4 * rb + g].x + wim * vc[4 * rb + g].y;
+        }
       store_z(buf ^ 1, zr);   // (after the last sample: a copy of its own z, never read)
       if constexpr (!PF) load_v(nxt, vc);
     };
