@@ -713,7 +713,8 @@ def main_beam(args, comm, rank, world, dev):
         },
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
-            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc_traffic(args.config, "bess_contract_kernel") if world == 1 else None,
             "kernel": "bess_contract_kernel (FP64 matrix cores, 3-product complex GEMM: 6 Nant^2 Ns Q flops per (f,t))",
             "ms_per_launch": k_ms, "flops_per_launch": flops,
         },
