@@ -586,15 +586,40 @@ static int k3_ntiles(int ns) {
   for (int ti = 0; ti < nrt; ++ti) n += k3_ncols(ti, nct);
   return n;
 }
-__device__ __forceinline__ void k3_tile_of(int p, int nct, int* ti, int* tj) {
-  int i = 0;
-  for (;; ++i) {
-    int c = k3_ncols(i, nct);
-    if (p < c) break;
-    p -= c;
+// Compact tile index -> (ti, tj) in closed form: a workgroup of config 5 (408 000 tiles, 1042 row
+// tiles) spent ~40 000 cycles walking the rows one by one, 10 % of the main kernel's workgroup and
+// most of the slab-sum kernel's (159 -> 55 ms).
+__host__ __device__ inline long long k3_floor_sum(long long n, long long m, long long a, long long b) {
+  // sum_{i=0}^{n-1} floor((a i + b) / m), Euclid-like, O(log m)
+  long long ans = 0;
+  for (;;) {
+    if (a >= m) { ans += (n - 1) * n / 2 * (a / m); a %= m; }
+    if (b >= m) { ans += n * (b / m); b %= m; }
+    long long ymax = a * n + b;
+    if (ymax < m) break;
+    n = ymax / m;
+    b = ymax % m;
+    long long t = m; m = a; a = t;
   }
+  return ans;
+}
+// number of needed tiles in the row tiles 0 .. ti-1 (= compact index of tile (ti, 0))
+__host__ __device__ inline long long k3_prefix(int ti, int nct) {
+  // ncols(i) = min(nct, floor((TR i + TR - 1) / TC) + 1); the clamp holds from row tile i0 on
+  long long i0 = ((long long)(nct - 1) * K3_TC - (K3_TR - 1) + K3_TR - 1) / K3_TR;
+  if (i0 < 0) i0 = 0;
+  long long lo = ti < i0 ? ti : i0;
+  return k3_floor_sum(lo, K3_TC, K3_TR, K3_TR - 1) + lo + (ti - lo) * (long long)nct;
+}
+__host__ __device__ inline void k3_tile_of(int p, int nct, int nrt, int* ti, int* tj) {
+  // prefix(i) ~ TR i^2 / (2 TC) below the clamp: start from the estimate, then step
+  double est = sqrt(2.0 * K3_TC * (double)p / K3_TR);
+  int i = (int)est;
+  if (i > nrt - 1) i = nrt - 1;
+  while (i > 0 && k3_prefix(i, nct) > p) --i;
+  while (i + 1 < nrt && k3_prefix(i + 1, nct) <= p) ++i;
   *ti = i;
-  *tj = p;
+  *tj = (int)(p - k3_prefix(i, nct));
 }
 
 template <bool SAMEBEAM>
@@ -607,7 +632,7 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
   int tile, split;
   block_work(blockIdx.x, ntiles, &tile, &split);
   int ti, tj;
-  k3_tile_of(tile, (ns + K3_TC - 1) / K3_TC, &ti, &tj);
+  k3_tile_of(tile, (ns + K3_TC - 1) / K3_TC, (ns + K3_TR - 1) / K3_TR, &ti, &tj);
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave / K3_WC, wc = wave % K3_WC;
   const int kr = lane >> 4, lc = lane & 15;
@@ -746,7 +771,7 @@ gram_finish_k3_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, 
                       double* __restrict__ G, double scale) {
   int tile = blockIdx.x;
   int ti, tj;
-  k3_tile_of(tile, (ns + K3_TC - 1) / K3_TC, &ti, &tj);
+  k3_tile_of(tile, (ns + K3_TC - 1) / K3_TC, (ns + K3_TR - 1) / K3_TR, &ti, &tj);
   const size_t stride = (size_t)ntiles * K3_TILE;
   const double* base = slabs + (size_t)tile * K3_TILE + blockIdx.y * 1024 + threadIdx.x;
   double sum[4] = {0.0, 0.0, 0.0, 0.0};
@@ -765,21 +790,34 @@ gram_finish_k3_kernel(const double* __restrict__ slabs, int nsplit, int ntiles, 
   for (; s < nsplit; ++s)
 #pragma unroll
     for (int q = 0; q < 4; ++q) sum[q] += base[(size_t)s * stride + q * 256];
+  // the chunk is 1024 / K3_TC consecutive tile rows: written as it is, and mirrored across the
+  // diagonal through LDS so that the mirror is stored in runs of (1024 / K3_TC) consecutive
+  // doubles instead of single ones (the 80 GB matrix of config 5 spent 158 ms here)
+  constexpr int CH_ROWS = 1024 / K3_TC;
+  __shared__ double s_t[CH_ROWS][K3_TC + 1];
 #pragma unroll
   for (int q = 0; q < 4; ++q) {
     int e = blockIdx.y * 1024 + q * 256 + threadIdx.x;
     int r = e / K3_TC, c = e % K3_TC;
     int gi = ti * K3_TR + r, gj = tj * K3_TC + c;
-    if (gi >= ns || gj >= ns || gj > gi) continue;
     double val = sum[q] * scale;
-    if (prior_std) {
-      val = prior_std[gi] * val * prior_std[gj];
-      if (gi == gj) val = 1.0 + val;
-    } else if (add_diag && gi == gj) {
-      val += add_diag[gi];
+    if (gi < ns && gj < ns && gj <= gi) {
+      if (prior_std) {
+        val = prior_std[gi] * val * prior_std[gj];
+        if (gi == gj) val = 1.0 + val;
+      } else if (add_diag && gi == gj) {
+        val += add_diag[gi];
+      }
+      G[(size_t)gi * ns + gj] = val;
     }
-    G[(size_t)gi * ns + gj] = val;
-    if (gi != gj) G[(size_t)gj * ns + gi] = val;
+    s_t[r - blockIdx.y * CH_ROWS][c] = val;
+  }
+  __syncthreads();
+  const int rl = threadIdx.x % CH_ROWS;
+  const int gi = ti * K3_TR + blockIdx.y * CH_ROWS + rl;
+  for (int c = threadIdx.x / CH_ROWS; c < K3_TC; c += 256 / CH_ROWS) {
+    int gj = tj * K3_TC + c;
+    if (gi < ns && gj < gi) G[(size_t)gj * ns + gi] = s_t[rl][c];
   }
 }
 
