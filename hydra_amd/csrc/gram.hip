@@ -588,7 +588,7 @@ static int k3_ntiles(int ns) {
 }
 // Compact tile index -> (ti, tj) in closed form: a workgroup of config 5 (408 000 tiles, 1042 row
 // tiles) spent ~40 000 cycles walking the rows one by one, 10 % of the main kernel's workgroup and
-// most of the slab-sum kernel's (159 -> 55 ms).
+// most of the slab-sum kernel's (159 -> 37 ms).
 __host__ __device__ inline long long k3_floor_sum(long long n, long long m, long long a, long long b) {
   // sum_{i=0}^{n-1} floor((a i + b) / m), Euclid-like, O(log m)
   long long ans = 0;
