@@ -611,15 +611,32 @@ __host__ __device__ inline long long k3_prefix(int ti, int nct) {
   long long lo = ti < i0 ? ti : i0;
   return k3_floor_sum(lo, K3_TC, K3_TR, K3_TR - 1) + lo + (ti - lo) * (long long)nct;
 }
+// Compact index p -> (ti, tj), bands of K3_BAND row tiles, column-major inside a band, so that the
+// ~32 tiles an XCD works on at a time form a compact patch (6 row tiles x 5 column tiles share
+// 1216 of the source columns; 32 tiles of one or two row tiles need nearly all of them).
+constexpr int K3_BAND = 6;
 __host__ __device__ inline void k3_tile_of(int p, int nct, int nrt, int* ti, int* tj) {
-  // prefix(i) ~ TR i^2 / (2 TC) below the clamp: start from the estimate, then step
+  // band: prefix(b0) <= p < prefix(b0 + K3_BAND); prefix(i) ~ TR i^2 / (2 TC) below the clamp
   double est = sqrt(2.0 * K3_TC * (double)p / K3_TR);
-  int i = (int)est;
-  if (i > nrt - 1) i = nrt - 1;
-  while (i > 0 && k3_prefix(i, nct) > p) --i;
-  while (i + 1 < nrt && k3_prefix(i + 1, nct) <= p) ++i;
-  *ti = i;
-  *tj = (int)(p - k3_prefix(i, nct));
+  int b0 = ((int)est / K3_BAND) * K3_BAND;
+  if (b0 > nrt - 1) b0 = (nrt - 1) / K3_BAND * K3_BAND;
+  while (b0 > 0 && k3_prefix(b0, nct) > p) b0 -= K3_BAND;
+  while (b0 + K3_BAND < nrt && k3_prefix(b0 + K3_BAND, nct) <= p) b0 += K3_BAND;
+  int q = (int)(p - k3_prefix(b0, nct));
+  const int rows = (nrt - b0 < K3_BAND) ? nrt - b0 : K3_BAND;
+  const int c0 = k3_ncols(b0, nct);          // columns present in every row tile of the band
+  if (q < rows * c0) {                       // full columns, row tile fastest
+    *tj = q / rows;
+    *ti = b0 + q % rows;
+    return;
+  }
+  q -= rows * c0;                            // ragged rest: row by row
+  for (int i = b0; i < b0 + rows; ++i) {
+    int extra = k3_ncols(i, nct) - c0;
+    if (q < extra) { *ti = i; *tj = c0 + q; return; }
+    q -= extra;
+  }
+  *ti = b0 + rows - 1; *tj = 0;              // not reached
 }
 
 template <bool SAMEBEAM>
