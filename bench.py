@@ -758,9 +758,11 @@ def main():
                          "general = always the per-baseline-weight kernel")
     ap.add_argument("--shard", default=None, choices=["freq", "baseline"],
                     help="how the visibility rows are split over GPUs (default: freq; c5s: baseline)")
-    ap.add_argument("--solver", default="dense", choices=["dense", "cg"],
+    ap.add_argument("--solver", default="dense", choices=["dense", "cg", "cg-rows"],
                     help="dense = blocked Cholesky (the reference's default for this head, "
-                         "example.py:944); cg = linear_solver.cg")
+                         "example.py:944); cg = linear_solver.cg on the root; cg-rows = the operator "
+                         "stays sharded by rows over the GPUs and every rank runs the CG with a "
+                         "row-block product + all-gather per iteration (config 5 on > 1 GPU)")
     args = ap.parse_args()
 
     import torch
@@ -787,8 +789,12 @@ def main():
     big = args.config in ("c5s", "c5")
     shard = args.shard or ("baseline" if args.config == "c5s" else "freq")
     if args.config == "c5":
-        args.solver = "cg"
+        # one GPU multiplies the 80 GB operator alone (7 ms per product); with more, each keeps its
+        # rows of the summed Gram and multiplies those
+        args.solver = "cg-rows" if world > 1 else "cg"
         args.no_cpu = True     # the CPU path cannot form or solve a 100 000^2 system in minutes
+    if args.solver == "cg-rows" and world == 1:
+        args.solver = "cg"
     inp = synth_inputs(hex_spec, ns, nf, nt, outriggers=19 if big else 0)
     ant_pos, antpairs_all = inp["ant_pos"], inp["antpairs"]
     nant = len(ant_pos)
@@ -839,6 +845,14 @@ def main():
     def one_sample():
         om_n = torch.randn((nbl, nf_loc, nt), dtype=torch.complex128, device=dev, generator=gen)
         om_a = torch.randn(ns, dtype=torch.float64, device=dev, generator=gen)
+        if args.solver == "cg-rows":
+            A, b = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
+                                                inv_noise, gains, prior, omega_n=om_n, omega_a=om_a,
+                                                shard_rows=True)
+            op = hy.linear_solver.RowShardedOperator(comm, A, ns)
+            x, iters = hy.linear_solver.cg(None, b, maxiters=1000, abs_tol=args.cg_tol,
+                                           linear_op=op, return_iters=True)
+            return op, b, x, iters
         A, b = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
                                             inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
         if rank == 0 and args.solver == "cg":
@@ -874,10 +888,11 @@ def main():
     elapsed = float(t_all.item())
     gram_ms = float(np.mean([s.elapsed_time(e) for s, e in events])) if events else float("nan")
 
+    # sanity of the last sample (outside the timed region; the row-sharded product is collective)
+    Ax = A(x) if args.solver == "cg-rows" else (A @ x if rank == 0 else None)
     if rank != 0:
         return
-    # sanity of the last sample (outside the timed region)
-    resid = float((torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)).item())
+    resid = float((torch.linalg.norm(Ax - b) / torch.linalg.norm(b)).item())
     # Algorithmic flops per launch of the kernel that ran (this rank's rows):
     #   gram_fused_kernel   (baseline form):  2 M Ns (Ns+1)                  [SURVEY 8(d)]
     #   gram_uniform_kernel (antenna form, 3-product complex multiply):

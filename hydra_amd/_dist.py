@@ -122,6 +122,43 @@ class Comm:
         dist.all_gather(parts, s, group=self.group)
         return [p.to(t.device) for p in parts] if isinstance(t, torch.Tensor) else parts
 
+    # ---- row sharding of a dense operator (large-N solve)
+    def row_range(self, n, rank=None):
+        """Rows [r0, r1) of an n-row matrix owned by ``rank`` (default: this rank): blocks of
+        ceil(n / size) rows, the last one shorter (possibly empty)."""
+        size = self.Get_size()
+        rank = self.Get_rank() if rank is None else rank
+        per = -(-n // size)
+        return min(rank * per, n), min((rank + 1) * per, n)
+
+    def reduce_rows_(self, A):
+        """Sum the (n, ncols) partial matrices of all ranks block row by block row, each block
+        to the rank that owns it (a reduce-scatter done as ``size`` in-place reduces on views:
+        no second copy of an 80 GB matrix).  Returns this rank's rows as a view of ``A``; the
+        other rows of ``A`` are left in an unspecified state."""
+        n = A.shape[0]
+        for k in range(self.Get_size()):
+            r0, r1 = self.row_range(n, k)
+            if r1 > r0:
+                self.reduce_(A[r0:r1], root=k)
+        r0, r1 = self.row_range(n)
+        return A[r0:r1]
+
+    def allgather_rows(self, part, n):
+        """Concatenate the ranks' row-block vectors (lengths as in ``row_range``) into the full
+        length-n vector on every rank."""
+        size = self.Get_size()
+        per = -(-n // size)
+        pad = torch.zeros(per, dtype=part.dtype, device=part.device)
+        pad[: part.numel()] = part
+        s, _ = self._stage(pad)
+        out = torch.empty(size * per, dtype=s.dtype, device=s.device)
+        if self.backend == "nccl":
+            dist.all_gather_into_tensor(out, s, group=self.group)
+        else:
+            dist.all_gather(list(out.split(per)), s, group=self.group)
+        return out[:n].to(part.device)
+
     # ---- mpi4py-style buffer collectives
     def Bcast(self, buf, root=0):
         self.bcast_(buf, root)

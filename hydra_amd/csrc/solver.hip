@@ -25,20 +25,21 @@ gemv_kernel(const double* __restrict__ A, int n, const double* __restrict__ x,
   }
 }
 
-// y[q] (+)= A[q] x[q] for a stack of nb independent (n,n) matrices (blockIdx.y = q): the
-// per-frequency likelihood term of the cosmological-field operator (cosmo_sampler.py:219-221).
+// y[q] (+)= A[q] x[q] for a stack of nb independent (nrows,n) matrices (blockIdx.y = q): the
+// per-frequency likelihood term of the cosmological-field operator (cosmo_sampler.py:219-221),
+// and (nb = 1, nrows < n) a rank's row block of a matrix sharded by rows over GPUs.
 // HBM-bound (8 n^2 bytes per matrix): a wave takes two rows at a time, 16-byte loads when the
 // rows are 16-byte aligned (n even), eight loads in flight per lane.
 template <bool VEC2>
 __global__ void __launch_bounds__(256)
-gemv_batched_kernel(const double* __restrict__ A, int n, const double* __restrict__ x,
+gemv_batched_kernel(const double* __restrict__ A, int nrows, int n, const double* __restrict__ x,
                     double* __restrict__ y, int accumulate) {
   int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const double* Aq = A + (size_t)blockIdx.y * n * n;
+  const double* Aq = A + (size_t)blockIdx.y * nrows * n;
   const double* xq = x + (size_t)blockIdx.y * n;
-  double* yq = y + (size_t)blockIdx.y * n;
-  for (int r = 2 * (blockIdx.x * 4 + wave); r < n; r += 2 * gridDim.x * 4) {
-    const bool two = r + 1 < n;
+  double* yq = y + (size_t)blockIdx.y * nrows;
+  for (int r = 2 * (blockIdx.x * 4 + wave); r < nrows; r += 2 * gridDim.x * 4) {
+    const bool two = r + 1 < nrows;
     const double* a0 = Aq + (size_t)r * n;
     const double* a1 = Aq + (size_t)(two ? r + 1 : r) * n;
     double s0 = 0.0, s1 = 0.0;
@@ -686,10 +687,25 @@ int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* 
   bool vec2 = n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
               reinterpret_cast<uintptr_t>(x) % 16 == 0;
   if (vec2)
-    gemv_batched_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y, accumulate);
+    gemv_batched_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(A, n, n, x, y, accumulate);
   else
-    gemv_batched_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(A, n, x, y, accumulate);
+    gemv_batched_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(A, n, n, x, y, accumulate);
   HYDRA_CHECK_LAUNCH("hydra_gemv_batched");
+  return HYDRA_OK;
+}
+
+int hydra_gemv_rows(const double* A, int nrows, int ncols, const double* x, double* y,
+                    int accumulate, void* stream) {
+  HYDRA_CHECK_ARG(A && x && y && nrows > 0 && ncols > 0, "hydra_gemv_rows: bad arguments (%d x %d)",
+                  nrows, ncols);
+  bool vec2 = ncols % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+              reinterpret_cast<uintptr_t>(x) % 16 == 0;
+  dim3 grid((unsigned)std::min(2048, (nrows + 7) / 8), 1);
+  if (vec2)
+    gemv_batched_kernel<true><<<grid, 256, 0, as_stream(stream)>>>(A, nrows, ncols, x, y, accumulate);
+  else
+    gemv_batched_kernel<false><<<grid, 256, 0, as_stream(stream)>>>(A, nrows, ncols, x, y, accumulate);
+  HYDRA_CHECK_LAUNCH("hydra_gemv_rows");
   return HYDRA_OK;
 }
 

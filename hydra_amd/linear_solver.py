@@ -110,6 +110,38 @@ def solve_dense(Amat, bvec):
     return _dev.like(bvec, b)
 
 
+# ------------------------------------------------------------------ row-sharded operator
+
+class RowShardedOperator:
+    """A dense operator sharded by rows over the ranks of ``comm`` (one process per GPU): rank k
+    keeps rows ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n).  Calling it with a full vector
+    returns the full product on every rank: the local row-block product
+    (``hydra_gemv_rows``, HBM-bound on 8 n_k n bytes) followed by one all-gather of n doubles
+    over RCCL.  Pass it as ``cg(None, b, linear_op=op)``: every rank then runs the same fused CG
+    steps on identical data and returns the same x, as ``cg(comm=...)`` does in the reference
+    (linear_solver.py:506-508).  This is the 1-D analogue of the reference's 2-D block layout
+    (``cg_mpi``, linear_solver.py:238-375) for matrices too large for one GPU's patience -- the
+    80 GB operator of 100 000 sources costs 7 ms per product on one GPU, 1/size of that here."""
+
+    def __init__(self, comm, A_rows, n):
+        self.comm = comm
+        self.A = _dev.f64(A_rows)
+        self.n = int(n)
+        r0, r1 = comm.row_range(self.n)
+        assert tuple(self.A.shape) == (r1 - r0, self.n), (tuple(self.A.shape), (r0, r1, self.n))
+        assert self.A.is_contiguous()
+        self.y = torch.empty(max(r1 - r0, 1), dtype=torch.float64, device=self.A.device)
+
+    def __call__(self, v):
+        vd = _dev.f64(v)
+        assert vd.numel() == self.n
+        nloc = self.A.shape[0]
+        if nloc > 0:
+            _dev.call("hydra_gemv_rows", _dev.ptr(self.A), nloc, self.n, _dev.ptr(vd),
+                      _dev.ptr(self.y), 0, _dev.stream_ptr())
+        return _dev.like(v, self.comm.allgather_rows(self.y[:nloc], self.n))
+
+
 # ------------------------------------------------------------------ 2-D block CG over ranks
 
 def matvec_mpi(comm_row, mat_block, vec_block):

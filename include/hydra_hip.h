@@ -262,6 +262,12 @@ int hydra_gemv(const double* A, int n, const double* x, double* y, void* stream)
 int hydra_gemv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
                        void* stream);
 
+/* y (+)= A x for a ROW BLOCK A (nrows, ncols) of a larger matrix: the product each GPU forms when
+ * the GCR operator is sharded by rows over the GPUs of a node (the matrix of 100 000 sources is
+ * 80 GB; linear_solver.py:11-49 does the same per 2-D block over MPI ranks).                   */
+int hydra_gemv_rows(const double* A, int nrows, int ncols, const double* x, double* y,
+                    int accumulate, void* stream);
+
 /* The same products for SYMMETRIC matrices (A[q] == A[q]^T exactly, stored in full): only the
  * 64 x 64 blocks on and below the diagonal are read -- half the HBM traffic.  workspace >=
  * hydra_symv_workspace_bytes(n, nb) holds the per-block-column pieces that a second launch sums

@@ -3,7 +3,7 @@ Worker run under torch.distributed.run by tests/test_dist.py (gloo backend, 127.
 
     python -m torch.distributed.run --nproc-per-node N tests/dist_worker.py <case>
 
-Cases "comm" and "blocks" need no GPU; "ptsrc", "blshard", "cosmo" and "cgmpi" run every rank on GPU 0 of the box
+Cases "comm" and "blocks" need no GPU; "ptsrc", "blshard", "rowshard", "cosmo" and "cgmpi" run every rank on GPU 0 of the box
 (collectives staged through the host by hydra_amd._dist.Comm) and compare with a single-process
 run of the same path.
 """
@@ -70,6 +70,19 @@ def case_comm(comm):
     assert [float(p.item()) for p in parts] == [float(r) for r in range(size)]
     obj = comm.bcast({"k": rank}, root=0)
     assert obj == {"k": 0}
+    # row sharding of a dense operator: block row k of the sum lands on rank k, vectors come back
+    # whole (n not a multiple of the world size; a rank may own no row at all)
+    for n in (7, size - 1 if size > 1 else 1):
+        ranges = [comm.row_range(n, k) for k in range(size)]
+        assert ranges[0][0] == 0 and ranges[-1][1] == n
+        assert all(ranges[k][1] == ranges[k + 1][0] for k in range(size - 1))
+        A = torch.arange(n * 3, dtype=torch.float64).reshape(n, 3) * (rank + 1)
+        mine = comm.reduce_rows_(A)
+        r0, r1 = comm.row_range(n)
+        want = torch.arange(n * 3, dtype=torch.float64).reshape(n, 3)[r0:r1] * sum(range(1, size + 1))
+        assert mine.shape == want.shape and torch.equal(mine, want)
+        full = comm.allgather_rows(torch.arange(r0, r1, dtype=torch.float64), n)
+        assert torch.equal(full, torch.arange(n, dtype=torch.float64))
     comm.barrier()
 
 
@@ -210,6 +223,46 @@ def case_cgmpi(comm):
     comm.barrier()
 
 
+def case_rowshard(comm):
+    """precompute_mpi(shard_rows=True) + RowShardedOperator CG over the ranks == the
+    single-process system and its solution, on every rank (large-N solve)."""
+    import hydra_amd as hy
+    rank, size = comm.Get_rank(), comm.Get_size()
+    p = _ptsrc_inputs()
+    ns = p["prior"].size
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in p["ant_pos"]]
+    fidx = np.array_split(np.arange(p["freqs"].size), size)[rank]
+    full = hy.ptsrc_sampler.calc_proj_operator(p["ra"], p["dec"], p["fluxes"], p["ant_pos"],
+                                               p["antpairs"], p["freqs"], p["times"], beams,
+                                               materialize=False)
+    A1, b1 = hy.ptsrc_sampler.precompute_mpi(
+        None, p["ants"], p["antpairs"], p["freqs"], p["times"], full, p["data"],
+        p["inv_noise"], p["gains"], p["prior"], omega_n=p["om_n"], omega_a=p["om_a"])
+    mine = hy.ptsrc_sampler.calc_proj_operator(
+        p["ra"], p["dec"], p["fluxes"][:, fidx], p["ant_pos"], p["antpairs"],
+        p["freqs"][fidx], p["times"], beams, materialize=False)
+    dev = torch.device("cuda")
+    A_rows, b2 = hy.ptsrc_sampler.precompute_mpi(
+        comm, p["ants"], p["antpairs"], p["freqs"][fidx], p["times"], mine,
+        torch.as_tensor(p["data"][:, fidx], device=dev), p["inv_noise"][:, fidx], p["gains"][:, fidx],
+        p["prior"], omega_n=p["om_n"][:, fidx], omega_a=p["om_a"] if rank == 0 else None,
+        shard_rows=True)
+    r0, r1 = comm.row_range(ns)
+    assert tuple(A_rows.shape) == (r1 - r0, ns)
+    ea = np.max(np.abs(A_rows.cpu().numpy() - A1[r0:r1])) / np.max(np.abs(A1))
+    eb = np.max(np.abs(b2.cpu().numpy() - b1)) / np.max(np.abs(b1))
+    assert ea < 1e-12 and eb < 1e-12, (ea, eb)
+    op = hy.linear_solver.RowShardedOperator(comm, A_rows, ns)
+    v = torch.as_tensor(np.random.RandomState(3).randn(ns), device=dev)
+    assert np.max(np.abs(op(v).cpu().numpy() - A1 @ v.cpu().numpy())) / np.max(np.abs(A1)) < 1e-12
+    x, iters = hy.linear_solver.cg(None, b2, maxiters=500, abs_tol=1e-10, linear_op=op,
+                                   return_iters=True)
+    x_ref = np.linalg.solve(A1, b1)
+    assert 0 < iters < 500
+    assert np.max(np.abs(x.cpu().numpy() - x_ref)) / np.max(np.abs(x_ref)) < 1e-8
+    comm.barrier()
+
+
 def case_cosmo(comm):
     """Frequency-sharded cosmo_sampler.precompute_mpi (each rank holds a slice of the field's
     channels; blocks of the other channels stay zero until comm.Reduce, cosmo_sampler.py:295-299,
@@ -239,7 +292,8 @@ if __name__ == "__main__":
     assert comm is not None, "run under torch.distributed.run with WORLD_SIZE > 1"
     try:
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
-         "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo}[case](comm)
+         "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
+         "rowshard": case_rowshard}[case](comm)
     except BaseException:
         import traceback
         if logdir:

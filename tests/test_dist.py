@@ -60,6 +60,11 @@ def test_baseline_sharded_ptsrc_system_world3():
 
 
 @pytest.mark.gpu
+def test_row_sharded_ptsrc_solve_world3():
+    _run("rowshard", 3)
+
+
+@pytest.mark.gpu
 def test_freq_sharded_cosmo_system_world3():
     _run("cosmo", 3)
 
