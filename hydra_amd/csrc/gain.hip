@@ -242,10 +242,21 @@ gain_basis_adj_kernel(const f64x2* __restrict__ y, const f64x2* __restrict__ F,
         if (m < nmodes) {
           const f64x2* fr = F + (size_t)m * nft + c0;
           f64x2 t = acc[q];
-          for (int k = lane; k < cn; k += 64) {
-            f64x2 r = cmul_conj(fr[k], s_y[k]);
-            t.x += r.x;
-            t.y += r.y;
+          // 8 basis loads in flight per lane (unconditional, clamped): one dependent load per
+          // trip left this kernel at 0.12 ms per call, latency bound.  Same summation order.
+          for (int kb = lane; kb < cn; kb += 512) {
+            f64x2 fv[8];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) fv[u] = fr[min(kb + 64 * u, cn - 1)];
+#pragma unroll
+            for (int u = 0; u < 8; ++u) {
+              int k = kb + 64 * u;
+              if (k < cn) {
+                f64x2 r = cmul_conj(fv[u], s_y[k]);
+                t.x += r.x;
+                t.y += r.y;
+              }
+            }
           }
           acc[q] = t;
         }
