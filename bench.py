@@ -461,7 +461,9 @@ def main_gain(args, comm, rank, world, dev):
                            "matvecs_per_s": batch / (mv_ms * 1e-3)},
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
-            "frac": achieved / 8000.0, "traffic": None, "kernel": "gain_pairs_tiled_kernel (+ "
+            "frac": achieved / 8000.0,
+            "traffic": pmc_traffic(args.config, "gain_pairs_tiled_kernel") if world == 1 else None,
+            "kernel": "gain_pairs_tiled_kernel (+ "
             "basis transforms), one operator application", "ms_per_launch": one_ms,
             "bytes_per_launch": alg_bytes,
         },
