@@ -20,11 +20,17 @@ _NP2TORCH = {
 }
 
 
+_have_gpu = False
+
+
 def device():
-    if not torch.cuda.is_available():
-        raise RuntimeError(
-            "hydra_amd needs an AMD GPU (MI355X / gfx950): no HIP device is visible and the "
-            "package has no CPU fallback.")
+    global _have_gpu
+    if not _have_gpu:      # checked until it succeeds once; the iteration loops call this a lot
+        if not torch.cuda.is_available():
+            raise RuntimeError(
+                "hydra_amd needs an AMD GPU (MI355X / gfx950): no HIP device is visible and the "
+                "package has no CPU fallback.")
+        _have_gpu = True
     return torch.device("cuda", torch.cuda.current_device())
 
 
@@ -38,6 +44,8 @@ def is_torch(x):
 
 def to_dev(x, dtype):
     """Contiguous tensor of ``dtype`` on the current GPU from numpy / torch / sequence."""
+    if isinstance(x, torch.Tensor) and x.is_cuda and x.dtype == dtype and x.is_contiguous():
+        return x           # already what the kernels take (the common case inside solver loops)
     dev = device()
     if isinstance(x, torch.Tensor):
         t = x.to(device=dev, dtype=dtype)

@@ -83,8 +83,28 @@ def calculate_pspec_on_grid(kbins, pspec, x, y, freqs, **cosmo_params):
 
 # ----------------------------------------------------------------------------- operator
 
+def _half_spectrum(pspec, exponent):
+    """pspec**exponent on the half spectrum of a real transform, symmetrised: for real x,
+    Re IFFT(P FFT(x)) = IFFT(((P(k) + P(-k)) / 2) FFT(x)), so the reference's ``.real`` of a full
+    complex transform (cosmo_sampler.py:190-194) is one real-to-complex and one complex-to-real
+    transform with that filter -- half the FFT work and three kernels fewer per application.
+    Cached on the (GPU) tensor until it is modified in place."""
+    key = (float(exponent), pspec._version)
+    cache = getattr(pspec, "_hydra_half", None)
+    if cache is not None and cache[0] == key:
+        return cache[1]
+    P = pspec ** exponent
+    Pm = torch.roll(torch.flip(P, dims=(0, 1, 2)), shifts=(1, 1, 1), dims=(0, 1, 2))   # P(-k)
+    half = (0.5 * (P + Pm))[..., : P.shape[2] // 2 + 1].contiguous()
+    try:
+        pspec._hydra_half = (key, half)
+    except AttributeError:
+        pass
+    return half
+
+
 def _apply_S_dev(x, pspec, exponent):
-    return torch.fft.ifftn(pspec ** exponent * torch.fft.fftn(x)).real.contiguous()
+    return torch.fft.irfftn(_half_spectrum(pspec, exponent) * torch.fft.rfftn(x), s=tuple(x.shape))
 
 
 def apply_S(x, pspec, exponent=1):
@@ -110,7 +130,14 @@ def apply_lhs_operator(x, lhs_Ninv_operator, pspec3d):
     if getattr(lhs_Ninv_operator, "hydra_symmetric", None) is None and _dev.is_torch(lhs_Ninv_operator):
         lhs_Ninv_operator.hydra_symmetric = bool(torch.equal(G, G.transpose(1, 2)))
     if getattr(lhs_Ninv_operator, "hydra_symmetric", False):
-        ws = _dev.workspace(_dev._lib.query("hydra_symv_workspace_bytes", npix, nf))
+        # the piece workspace lives with the operator: one allocation, not one per application
+        ws = getattr(lhs_Ninv_operator, "_hydra_symv_ws", None)
+        if ws is None or ws.device != G.device:
+            ws = _dev.workspace(_dev._lib.query("hydra_symv_workspace_bytes", npix, nf))
+            try:
+                lhs_Ninv_operator._hydra_symv_ws = ws
+            except AttributeError:
+                pass
         _dev.call("hydra_symv_batched", _dev.ptr(G), npix, nf, _dev.ptr(xd), _dev.ptr(y), 1,
                   _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
     else:

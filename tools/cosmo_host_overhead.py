@@ -1,0 +1,42 @@
+"""Host time against GPU time of one CG iteration of the cosmological-field head's operator
+(FFT prior + batched symmetric product + fused CG step): is the loop launch bound?"""
+import os
+import sys
+import time
+
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), ".."))
+import torch
+
+import hydra_amd  # noqa: F401
+from hydra_amd import _dev, cosmo_sampler as cs
+
+nf, nx = 64, 32
+npix = nx * nx
+torch.manual_seed(0)
+G = torch.randn(nf, npix, npix, dtype=torch.float64, device="cuda")
+G = G + G.transpose(1, 2).clone()
+p3d = torch.rand(nf, nx, nx, dtype=torch.float64, device="cuda") + 0.5
+x = torch.randn(nf, nx, nx, dtype=torch.float64, device="cuda")
+n = x.numel()
+r, p = torch.randn(n, dtype=torch.float64, device="cuda"), torch.randn(n, dtype=torch.float64, device="cuda")
+xs = torch.zeros(n, dtype=torch.float64, device="cuda")
+st = _dev.zeros((_dev._lib.query("hydra_cg_state_len"),), torch.float64)
+
+
+def iteration():
+    ap = cs.apply_lhs_operator(p.reshape(nf, nx, nx), G, p3d).flatten()
+    _dev.call("hydra_cg_step", n, _dev.ptr(ap), _dev.ptr(xs), _dev.ptr(r), _dev.ptr(p), _dev.ptr(st),
+              1e-30, 0, _dev.stream_ptr())
+
+
+for _ in range(20):
+    iteration()
+torch.cuda.synchronize()
+reps = 300
+t0 = time.perf_counter()
+for _ in range(reps):
+    iteration()
+t_host = time.perf_counter() - t0
+torch.cuda.synchronize()
+t_all = time.perf_counter() - t0
+print(f"per iteration: host (enqueue only) {t_host / reps * 1e6:.1f} us, host + GPU drain {t_all / reps * 1e6:.1f} us")
