@@ -189,7 +189,11 @@ bess_contract_kernel(const f64x2* __restrict__ V, int nft, int nt, int nant, int
 __global__ void __launch_bounds__(256)
 bess_to_vis_kernel(const f64x2* __restrict__ C, const f64x2* __restrict__ coef, int nf, int nt,
                    int nant, int nc, int nb, int samp, int col_only, f64x2* __restrict__ out) {
+  // threads <-> (row group g, column B): 256 / BW row groups walk the rows b = g, g + NG, ... of
+  // the Nc x NB block with 4 loads in flight each, then the groups are summed through LDS in
+  // group order.  (With threads over the columns only, 40 of 256 threads worked at NB = 40.)
   __shared__ f64x2 sc[256];
+  __shared__ f64x2 sred[256];
   const int k = blockIdx.x % (nant - 1);
   const int ft = blockIdx.x / (nant - 1);
   const int f = ft / nt;
@@ -197,24 +201,49 @@ bess_to_vis_kernel(const f64x2* __restrict__ C, const f64x2* __restrict__ coef, 
   const f64x2* blk = col_only ? C + ((size_t)ft * nant + A) * nc * nb
                               : C + (((size_t)ft * nant + A) * nant + samp) * nc * nb;
   f64x2* o = out + (size_t)blockIdx.x * nb;
-  for (int b0 = 0; b0 < nc; b0 += 256) {
-    __syncthreads();
-    int bb = b0 + threadIdx.x;
-    if (bb < nc) {
-      f64x2 c = coef[((size_t)bb * nf + f) * nant + A];
-      sc[threadIdx.x] = f64x2{c.x, -c.y};
+  // column tile width: the smallest power of two >= min(nb, 256)
+  int BW = 1;
+  while (BW < nb && BW < 256) BW <<= 1;
+  const int NG = 256 / BW;
+  const int g = threadIdx.x / BW, Bl = threadIdx.x % BW;
+  for (int B0 = 0; B0 < nb; B0 += BW) {
+    const int B = B0 + Bl;
+    const int Bc = min(B, nb - 1);
+    f64x2 acc = {0.0, 0.0};
+    for (int b0 = 0; b0 < nc; b0 += 256) {
+      __syncthreads();
+      int bb = b0 + threadIdx.x;
+      if (bb < nc) {
+        f64x2 c = coef[((size_t)bb * nf + f) * nant + A];
+        sc[threadIdx.x] = f64x2{c.x, -c.y};
+      }
+      __syncthreads();
+      const int nbl = min(256, nc - b0);
+      for (int b = g; b < nbl; b += 4 * NG) {
+        f64x2 v[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u)      // unconditional, clamped; rows beyond the block are skipped below
+          v[u] = blk[(size_t)min(b0 + b + u * NG, nc - 1) * nb + Bc];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          if (b + u * NG < nbl) {
+            f64x2 c = sc[b + u * NG];
+            acc.x += c.x * v[u].x - c.y * v[u].y;
+            acc.y += c.x * v[u].y + c.y * v[u].x;
+          }
+        }
+      }
     }
     __syncthreads();
-    int nbl = min(256, nc - b0);
-    for (int B = threadIdx.x; B < nb; B += 256) {
-      f64x2 acc = (b0 == 0) ? f64x2{0.0, 0.0} : o[B];
-      for (int b = 0; b < nbl; ++b) {
-        f64x2 v = blk[(size_t)(b0 + b) * nb + B];
-        f64x2 c = sc[b];
-        acc.x += c.x * v.x - c.y * v.y;
-        acc.y += c.x * v.y + c.y * v.x;
+    sred[threadIdx.x] = acc;
+    __syncthreads();
+    if (g == 0 && B < nb) {
+      f64x2 t = sred[Bl];
+      for (int q = 1; q < NG; ++q) {
+        t.x += sred[q * BW + Bl].x;
+        t.y += sred[q * BW + Bl].y;
       }
-      o[B] = acc;
+      o[B] = t;
     }
   }
 }
