@@ -316,7 +316,7 @@ def main_sh(args, comm, rank, world, dev):
             "kernel": "adjoint_R_kernel", "ms_per_launch": adj_ms, "bytes_per_launch": adj_bytes,
         },
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         cb = sh_cpu_baseline(min(m_all, 1000), m_all, nm)
         iters_ref = max(int(iters), 1)
         t_sample = cb["rhs_s"] + (iters_ref + 1) * cb["lhs_apply_s"]
@@ -588,7 +588,7 @@ def main_cosmo(args, comm, rank, world, dev):
         },
         "cpu_baseline": None,
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         out["cpu_baseline"] = cosmo_cpu_baseline(ant_pos, antpairs, freqs, times, g_ra, g_dec, g0,
                                                  sigma, pspec3d, op.cpu().numpy(), int(iters), m_all)
     print(json.dumps(out))
@@ -722,7 +722,7 @@ def main_beam(args, comm, rank, world, dev):
         },
         "cpu_baseline": None,
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         from oracle import gcr_beam as ob
         nf_s, nt_s = 1, min(nt, 2)
         t0 = time.perf_counter()
@@ -945,7 +945,7 @@ def main():
             "flops_per_launch": gram_flops,
         },
     }
-    if not args.no_cpu:
+    if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         nf_s, nt_s = (2, 10) if args.config == "c2" else (min(nf, 2), min(nt, 10))
         if big:      # a 2000-baseline, one-channel slice (the full slice would need 16 GB)
             inp = dict(inp, antpairs=antpairs_all[:2000])
