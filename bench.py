@@ -582,7 +582,8 @@ def main_cosmo(args, comm, rank, world, dev):
         "sample_rel_residual": resid,
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS, "traffic": None,
+            "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc_traffic(args.config, kernel) if world == 1 else None,
             "kernel": kernel + " (one channel per launch)", "ms_per_launch": gram_ms,
             "flops_per_launch": gram_flops,
         },
