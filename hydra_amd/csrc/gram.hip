@@ -519,8 +519,8 @@ uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
               const double* __restrict__ wft, int nft, int nant, int nantp, int ns, int same_beam,
               f64x2* __restrict__ U) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  int ft = blockIdx.y;
   if (s >= ns) return;
+  for (int ft = blockIdx.y; ft < nft; ft += gridDim.y) {   // grid.y is capped at 65535
   double w4 = wft ? sqrt(sqrt(wft[ft])) : 1.0;
   double c4 = 0.0;
   f64x2 v0 = {0.0, 0.0};
@@ -541,6 +541,7 @@ uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
       u = f64x2{sqrt(c4) * (v0.x * v0.x + v0.y * v0.y), 0.0};
     }
     U[((size_t)ft * nantp + a) * ns + s] = u;
+  }
   }
 }
 
@@ -1037,7 +1038,7 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   HYDRA_CHECK_ARG(nf > 0 && nt > 0 && nant > 1 && ns > 0, "hydra_gram_uniform: bad sizes");
   HYDRA_CHECK_ARG(!(prior_std && add_diag),
                   "hydra_gram_uniform: give at most one of prior_std, add_diag");
-  HYDRA_CHECK_ARG((long long)nf * nt <= 65535, "hydra_gram_uniform: nf*nt must be <= 65535");
+  HYDRA_CHECK_ARG((long long)nf * nt <= 2147483647LL / 8, "hydra_gram_uniform: nf*nt too large");
   size_t need = hydra_gram_uniform_workspace_bytes(nf, nt, nant, ns);
   if (!workspace || workspace_bytes < need)
     return fail(HYDRA_ERR_WORKSPACE, "hydra_gram_uniform: workspace too small (%zu < %zu bytes)",
@@ -1052,7 +1053,7 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   size_t slab_bytes = align_up((size_t)nsplit * ntiles * K3_TILE * sizeof(double), 256);
   f64x2* U = reinterpret_cast<f64x2*>(static_cast<unsigned char*>(workspace) + slab_bytes);
   hipStream_t st = as_stream(stream);
-  dim3 ugrid((ns + 255) / 256, nft);
+  dim3 ugrid((ns + 255) / 256, std::min(nft, 65535));
   uscale_kernel<<<ugrid, 256, 0, st>>>(reinterpret_cast<const f64x2*>(V),
                                        reinterpret_cast<const f64x2*>(gains), w_ft, nft, nant, nantp,
                                        ns, same_beam, U);

@@ -127,7 +127,7 @@ class FactoredProj:
         closed form in the antenna voltages is used instead (gram_uniform_kernel)."""
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
-        if self.complete and self.allow_uniform and nf * nt <= 65535 and nant > 1:
+        if self.complete and self.allow_uniform and nant > 1:
             w_ft = None
             uniform = True
             if inv_noise is not None:

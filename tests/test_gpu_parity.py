@@ -564,6 +564,40 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
 
 # ------------------------------------------------------------------ closed-form (antenna-space) Gram
 
+def test_closed_form_gram_beyond_65535_time_frequency_samples(hy):
+    """More (f,t) samples than a grid dimension holds (700 x 100): the closed-form kernel still
+    runs (the pre-scale kernel strides over (f,t)) and agrees with the general kernel."""
+    nant, ns, nf, nt = 4, 40, 700, 100
+    rng = np.random.RandomState(5)
+    ant_pos = {a: np.array([rng.uniform(-80, 80), rng.uniform(-80, 80), 0.0]) for a in range(nant)}
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    nbl = len(antpairs)
+    np.random.seed(3)
+    ra, dec, amps = hy.example.generate_random_ptsrc_catalogue(ns, (0.0, 1.0), (-0.6, 0.4))
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    fluxes = hy.utils.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    gains = (1.0 + 0.5j) + 0.2 * (rng.randn(nant, nf, nt) + 1j * rng.randn(nant, nf, nt))
+    inv_noise = np.broadcast_to(100.0 + 400.0 * rng.rand(nf, nt), (nbl, nf, nt)).copy()
+    data = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    om_n = (rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)) / np.sqrt(2)
+    om_a = rng.randn(ns)
+    prior = 0.05 + 0.1 * rng.rand(ns)
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in range(nant)]
+    fac = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, beams,
+                                              materialize=False)
+    out = {}
+    for uniform in (True, False):
+        fac.allow_uniform = uniform
+        out[uniform] = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
+                                                       inv_noise, gains, prior, omega_n=om_n,
+                                                       omega_a=om_a)
+        assert fac.last_gram_kernel == ("gram_uniform_kernel" if uniform else "gram_fused_kernel")
+    assert relerr(out[True][0], out[False][0]) < 1e-10
+    assert relerr(out[True][1], out[False][1]) < 1e-12
+
+
 @pytest.mark.parametrize("nant,ns,nf,nt,mixed", [(10, 100, 3, 4, False), (37, 300, 2, 3, False),
                                                  (37, 300, 2, 3, True), (39, 140, 1, 2, False),
                                                  (40, 140, 1, 2, False), (45, 130, 2, 2, False),
