@@ -5,6 +5,7 @@
 //     test in a single launch, state kept on the device);
 //   * a blocked Cholesky solve as the dense fallback (example.py:944).
 #include <algorithm>
+#include <mutex>
 
 #include "common.h"
 
@@ -203,6 +204,40 @@ symv_reduce_kernel(const double* __restrict__ part, int n, int nbk, double* __re
     double* yq = y + (size_t)blockIdx.y * n;
     yq[i] = accumulate ? yq[i] + v : v;
   }
+}
+
+// ---------------------------------------------------------------- symv without a workspace
+// hydra_symv_static: the pieces of symv_blocks_kernel go to a file-scope device array instead of
+// a caller workspace, for callers that cannot allocate (HIP graph capture, serving loops).
+// Every GPU the library runs on holds its own copy (8 MiB) until the process ends; host code
+// never uses the array's name as an address -- only the per-device pointer obtained below.
+constexpr int SYMV_STATIC_MAX_N = 8192;
+constexpr size_t SYMV_STATIC_DOUBLES = (size_t)(SYMV_STATIC_MAX_N / SV_T) * SYMV_STATIC_MAX_N;
+static __device__ __align__(256) double scratch[SYMV_STATIC_DOUBLES];
+
+constexpr int SCRATCH_MAX_DEVICES = 64;
+static double* g_scratch_ptr[SCRATCH_MAX_DEVICES];
+static std::mutex g_scratch_mutex;
+
+// device address of `scratch` on the CURRENT device (looked up once per device)
+static int scratch_ptr_for_current_device(double** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess)
+    return fail(HYDRA_ERR_HIP, "hydra_symv_static: hipGetDevice: %s", hipGetErrorString(e));
+  if (dev < 0 || dev >= SCRATCH_MAX_DEVICES)
+    return fail(HYDRA_ERR_ARG, "hydra_symv_static: device index %d out of range", dev);
+  std::lock_guard<std::mutex> lock(g_scratch_mutex);
+  if (!g_scratch_ptr[dev]) {
+    double* p = nullptr;
+    e = hipGetSymbolAddress(reinterpret_cast<void**>(&p), HIP_SYMBOL(scratch));
+    if (e != hipSuccess || !p)
+      return fail(HYDRA_ERR_HIP, "hydra_symv_static: hipGetSymbolAddress: %s",
+                  hipGetErrorString(e));
+    g_scratch_ptr[dev] = p;
+  }
+  *out = g_scratch_ptr[dev];
+  return HYDRA_OK;
 }
 
 // ---------------------------------------------------------------- CG
@@ -736,6 +771,31 @@ int hydra_symv_batched(const double* A, int n, int nb, const double* x, double* 
   else      symv_blocks_kernel<false><<<grid, 256, 0, s>>>(A, n, nbk, x, part);
   symv_reduce_kernel<<<dim3(nbk, nb), 256, 0, s>>>(part, n, nbk, y, accumulate);
   HYDRA_CHECK_LAUNCH("hydra_symv_batched");
+  return HYDRA_OK;
+}
+
+int hydra_symv_static_max_n(void) { return SYMV_STATIC_MAX_N; }
+
+int hydra_symv_static(const double* A, int n, const double* x, double* y, int accumulate,
+                      void* stream) {
+  HYDRA_CHECK_ARG(A && x && y && n > 0, "hydra_symv_static: bad arguments (n=%d)", n);
+  if (n > SYMV_STATIC_MAX_N)
+    return fail(HYDRA_ERR_ARG,
+                "hydra_symv_static: n=%d exceeds the static scratch (max n=%d); use "
+                "hydra_symv_batched with a caller workspace", n, SYMV_STATIC_MAX_N);
+  double* part = nullptr;
+  int rc = scratch_ptr_for_current_device(&part);
+  if (rc) return rc;
+  int nbk = (n + SV_T - 1) / SV_T;
+  int nwg = nbk * (nbk + 1) / 2;
+  hipStream_t s = as_stream(stream);
+  bool vec2 = n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0;
+  // every (block column, row < n) piece is written before the second launch reads it, so the
+  // contents left by the previous call never reach y and nothing needs clearing
+  if (vec2) symv_blocks_kernel<true><<<dim3(nwg, 1), 256, 0, s>>>(A, n, nbk, x, part);
+  else      symv_blocks_kernel<false><<<dim3(nwg, 1), 256, 0, s>>>(A, n, nbk, x, part);
+  symv_reduce_kernel<<<dim3(nbk, 1), 256, 0, s>>>(part, n, nbk, y, accumulate);
+  HYDRA_CHECK_LAUNCH("hydra_symv_static");
   return HYDRA_OK;
 }
 

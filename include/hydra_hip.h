@@ -277,6 +277,18 @@ size_t hydra_symv_workspace_bytes(int n, int nb);
 int hydra_symv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* hydra_symv_batched for one matrix WITHOUT a workspace argument and without any allocation: the
+ * per-block-column pieces go to a device array inside the library (8 MiB on every GPU the library
+ * runs on, held until the process ends).  No counterpart in the reference: it is for callers that
+ * cannot allocate -- code under HIP graph capture, tight serving loops, harnesses that forbid
+ * hipMalloc.  n <= hydra_symv_static_max_n() (8192), larger n is rejected with HYDRA_ERR_ARG.
+ * Same kernels, same summation order and bit-identical y as hydra_symv_batched(A, n, 1, ...).
+ * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different
+ * streams or threads) race; calls on one stream are ordered and safe.                        */
+int hydra_symv_static_max_n(void);
+int hydra_symv_static(const double* A, int n, const double* x, double* y, int accumulate,
+                      void* stream);
+
 /* Conjugate gradients exactly as linear_solver.cg (linear_solver.py:378-509):
  * convergence tested BEFORE each iteration, element-wise |r_i| < tol or ||r||_2 < tol.
  * State (device): x, r, p (N) f64 and `st` = hydra_cg_state_len() doubles (776):
