@@ -1,0 +1,617 @@
+// Dense fallback of the GCR solve on gfx950: scipy.linalg.solve(A, b, assume_a='her') of the
+// driver (example.py:944) for the symmetric positive-definite operator, as a blocked Cholesky.
+//   * n < CHOL_BLOCKED_MIN_N: 32-wide right-looking steps, tuned for the launch chain at n ~ 2000;
+//   * larger n: 256-wide panels with the trailing update on the FP64 matrix cores and
+//     multi-workgroup triangular solves (config 5: 100 000 unknowns).
+#include <algorithm>
+
+#include "common.h"
+
+namespace hydra {
+
+// ---------------------------------------------------------------- blocked Cholesky
+
+constexpr int NB = 32;
+
+__device__ __forceinline__ double readlane_f64(double x, int lane) {
+  int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
+  int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
+  return __hiloint2double(hi, lo);
+}
+
+// Cholesky of one NB x NB block by ONE wave, rows in registers: lane i (< NB) holds row i of the
+// lower triangle in v[]; column c's pivot and multipliers travel by v_readlane, so the NB steps
+// need no LDS and no barrier (the barrier-per-column form took 16 us per block, this one ~2).
+// Entries above the diagonal are never read.  Returns true if a pivot was not positive.
+__device__ __forceinline__ bool potrf_wave(double (&v)[NB], int i) {
+  bool bad = false;
+#pragma unroll
+  for (int c = 0; c < NB; ++c) {
+    double d = readlane_f64(v[c], c);
+    if (!(d > 0.0)) bad = true;
+    // reciprocal square root + one correction instead of sqrt and a divide per column: the two
+    // long dependent sequences were most of this routine's time
+    double inv = rsqrt(d);
+    double sd = d * inv;
+    sd = fma(fma(-sd, sd, d), 0.5 * inv, sd);
+    v[c] = (i == c) ? sd : v[c] * inv;
+#pragma unroll
+    for (int j = c + 1; j < NB; ++j) {
+      double ljc = readlane_f64(v[c], j);
+      v[j] -= v[c] * ljc;
+    }
+  }
+  return bad;
+}
+
+// factor the nb x nb diagonal block at (k,k) in place from the tile `t` in LDS (rows/cols >= nb
+// are treated as identity); called by the first wave of a workgroup.
+__device__ __forceinline__ void potrf_tile(const double (*t)[NB + 1], double* __restrict__ A, int n,
+                                           int k, int nb, int32_t* __restrict__ info, int lane) {
+  int i = lane & (NB - 1);
+  double v[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = (i < nb && j < nb) ? t[i][j] : (i == j ? 1.0 : 0.0);
+  bool bad = potrf_wave(v, i);
+  if (bad && lane == 0) atomicOr(info, 1);
+  if (lane < nb) {
+    double* row = A + (size_t)(k + lane) * n + k;
+#pragma unroll
+    for (int j = 0; j < NB; ++j)
+      if (j <= lane) row[j] = v[j];
+  }
+}
+
+// first diagonal block (the later ones are factored by the trailing update that completes them)
+__global__ void __launch_bounds__(NB * NB)
+potrf_diag_kernel(double* __restrict__ A, int n, int k, int32_t* __restrict__ info) {
+  __shared__ double s[NB][NB + 1];
+  int i = threadIdx.y, j = threadIdx.x;
+  int nb = min(NB, n - k);
+  s[i][j] = (i < nb && j < nb) ? A[(size_t)(k + i) * n + k + j] : (i == j ? 1.0 : 0.0);
+  __syncthreads();
+  int tid = i * NB + j;
+  if (tid < 64) potrf_tile(s, A, n, k, nb, info, tid);
+}
+
+// rows below a full diagonal block: A[r, k:k+NB] <- A[r, k:k+NB] L11^-T, thread <-> row.  One wave
+// per workgroup so the panel spreads over many CUs (the substitution reads L11 from LDS once per
+// multiply-add); rows travel through LDS so that global accesses run along the rows.
+constexpr int TRSM_T = 64;
+static_assert(TRSM_T == 2 * NB, "trsm staging assumes two rows per trip");
+__global__ void __launch_bounds__(TRSM_T)
+trsm_panel_kernel(double* __restrict__ A, int n, int k) {
+  __shared__ double l[NB][NB + 1];
+  __shared__ double dinv[NB];
+  __shared__ double rows[TRSM_T][NB + 1];
+  const int tid = threadIdx.x;
+  // unconditional loads (in bounds: the block is full, row indices are clamped) so that the
+  // compiler can issue them all before the first use
+  const int r0 = k + NB + blockIdx.x * TRSM_T;
+  {
+    const int j = tid % NB, i0 = tid / NB;   // TRSM_T / NB = 2 rows per trip
+    double a[NB / 2], rr[NB];
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) a[q] = A[(size_t)(k + i0 + 2 * q) * n + k + j];
+#pragma unroll
+    for (int q = 0; q < NB; ++q) rr[q] = A[(size_t)min(r0 + i0 + 2 * q, n - 1) * n + k + j];
+#pragma unroll
+    for (int q = 0; q < NB / 2; ++q) {
+      int i = i0 + 2 * q;
+      l[i][j] = (j <= i) ? a[q] : 0.0;
+      if (i == j) dinv[i] = 1.0 / a[q];
+    }
+#pragma unroll
+    for (int q = 0; q < NB; ++q) rows[i0 + 2 * q][j] = rr[q];
+  }
+  __syncthreads();
+  double v[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = rows[tid][j];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) {
+    double t = v[j];
+#pragma unroll
+    for (int c = 0; c < j; ++c) t -= v[c] * l[j][c];
+    v[j] = t * dinv[j];
+  }
+#pragma unroll
+  for (int j = 0; j < NB; ++j) rows[tid][j] = v[j];
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < NB; ++q) {
+    int i = tid / NB + 2 * q, j = tid % NB;
+    if (r0 + i < n) A[(size_t)(r0 + i) * n + k + j] = rows[i][j];
+  }
+}
+
+// trailing update of the lower triangle: A22 -= L21 L21^T, 64x64 output tiles by 256 threads
+// (4x4 entries each, the NB-deep panels in LDS).  The top-left NB x NB corner of tile (0,0) is the
+// NEXT diagonal block, complete after this update: its workgroup factors it on the spot, which
+// saves one launch per block column.  Only launched for full blocks (nb == NB).
+// col_end (exclusive) caps the updated columns: n for the small-matrix path; the end of the current
+// 256-wide panel for the large-matrix path, whose remaining columns get one rank-256 update on the
+// matrix cores instead (chol_syrk_mfma_kernel).
+constexpr int SY_T = 64;
+__global__ void __launch_bounds__(256)
+syrk_update_kernel(double* __restrict__ A, int n, int k, int col_end,
+                   int32_t* __restrict__ info) {
+  const int base = k + NB;
+  const int bi = blockIdx.y, bj = blockIdx.x;
+  if (bj > bi) return;
+  __shared__ double sa[SY_T][NB + 1], sb[SY_T][NB + 1];
+  const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
+  const int i0 = base + bi * SY_T, j0 = base + bj * SY_T;
+  {
+    const int c = tid % NB, r = tid / NB;   // 8 panel rows per trip, loads along the rows
+    double pa[SY_T / 8], pb[SY_T / 8];
+#pragma unroll
+    for (int q = 0; q < SY_T / 8; ++q) {
+      pa[q] = A[(size_t)min(i0 + r + 8 * q, n - 1) * n + k + c];
+      pb[q] = A[(size_t)min(j0 + r + 8 * q, n - 1) * n + k + c];
+    }
+#pragma unroll
+    for (int q = 0; q < SY_T / 8; ++q) {
+      sa[r + 8 * q][c] = pa[q];
+      sb[r + 8 * q][c] = pb[q];
+    }
+  }
+  double old[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
+      old[a][b] = (gi < n && gj <= gi) ? A[(size_t)gi * n + gj] : 0.0;
+    }
+  __syncthreads();
+  double acc[4][4] = {};
+#pragma unroll 8
+  for (int c = 0; c < NB; ++c) {
+    double ra[4], rb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ra[a] = sa[ty + 16 * a][c];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rb[b] = sb[tx + 16 * b][c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
+  }
+  const bool corner = bi == 0;   // then bj == 0 too: this tile holds the next diagonal block
+  if (corner) __syncthreads();   // sa is free: its first NB rows take the updated corner
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int li = ty + 16 * a, lj = tx + 16 * b;
+      int gi = i0 + li, gj = j0 + lj;
+      double val = old[a][b] - acc[a][b];
+      if (corner && li < NB && lj < NB) sa[li][lj] = val;
+      else if (gi < n && gj <= gi && gj < col_end) A[(size_t)gi * n + gj] = val;
+    }
+  if (!corner) return;
+  __syncthreads();
+  if (tid < 64) potrf_tile(sa, A, n, base, min(NB, n - base), info, tid);
+}
+
+// Both triangular solves of the Cholesky fallback in ONE launch by one workgroup of NB*NB threads
+// (a kernel pair per block column needs 4 n / NB launches of 5-18 us each, most of the solve time
+// at n ~ 2000).  Left-looking: block k of the solution needs sum_j L[k, j] y_j over the blocks
+// already solved, a (NB x k) product whose loads run along the rows of L (forward sweep) or along
+// the NB-wide column panel (backward sweep) - 256-byte pieces either way, never one line per lane.
+// Thread (a, c) = (tid / NB, tid % NB) leaves a partial sum in part[][]; the first wave adds them
+// up and does the NB x NB substitution in registers.  L is read once per sweep.
+constexpr int TRSV_T = NB * NB;
+
+// element (tid / NB, tid % NB) of the diagonal block at (k,k), clamped into the matrix (entries
+// outside the nb x nb lower triangle are masked when staged)
+__device__ __forceinline__ double trsv_diag_load(const double* __restrict__ A, int ld, int n, int k,
+                                                 int tid) {
+  int i = min(max(k, 0) + tid / NB, n - 1), j = min(max(k, 0) + tid % NB, n - 1);
+  return A[(size_t)i * ld + j];
+}
+
+// BL: the solution vector lives in dynamic LDS (copied in and out), next to the multiply-adds;
+// otherwise it stays in b.  (A template, not a flat pointer: flat loads wait on both memory
+// counters and would serialise against the loads of L.)
+template <bool BL>
+__global__ void __launch_bounds__(TRSV_T)
+trsv_fused_kernel(const double* __restrict__ A, int ld, int n, double* __restrict__ b,
+                  int sweep_begin, int sweep_end) {
+  extern __shared__ double b_lds[];
+  __shared__ double l[NB][NB + 1];
+  __shared__ double part[NB][NB + 1];
+  __shared__ double dinv[NB];
+  const int tid = threadIdx.x;
+  const int ta = tid / NB, tc = tid % NB;
+  if (BL)
+    for (int i = tid; i < n; i += TRSV_T) b_lds[i] = b[i];
+  auto bv = [&](int i) -> double& { return BL ? b_lds[i] : b[i]; };
+  __syncthreads();
+  const int last = ((n - 1) / NB) * NB;
+  // sweep 0: L y = b left to right, 1: L^T x = y right to left.  A is an n x n block with leading
+  // dimension ld (the whole matrix, or one diagonal block of the large-matrix path).
+  for (int sweep = sweep_begin; sweep < sweep_end; ++sweep) {
+    double a = trsv_diag_load(A, ld, n, sweep ? last : 0, tid);
+    for (int k = sweep ? last : 0; sweep ? k >= 0 : k < n; k += sweep ? -NB : NB) {
+      const int nb = min(NB, n - k);
+      l[ta][tc] = (ta < nb && tc <= ta) ? a : 0.0;
+      if (ta == tc) dinv[ta] = (ta < nb) ? 1.0 / a : 1.0;
+      a = trsv_diag_load(A, ld, n, sweep ? k - NB : k + NB, tid);   // next block, in flight meanwhile
+      double s0 = 0.0, s1 = 0.0;
+      if (!sweep) {   // row k + ta of L against y[0:k]; this thread takes columns tc, tc + NB, ...
+        const double* row = A + (size_t)min(k + ta, n - 1) * ld;
+        for (int j = tc; j < k; j += 8 * NB) {   // 8 loads in flight; the tail is masked, not serial
+          double rv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rv[u] = row[min(j + u * NB, k - NB + tc)];
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) {
+            int j0 = j + u * NB, j1 = j0 + NB;
+            s0 += (j0 < k) ? rv[u] * bv(min(j0, k - 1)) : 0.0;
+            s1 += (j1 < k) ? rv[u + 1] * bv(min(j1, k - 1)) : 0.0;
+          }
+        }
+      } else if (nb == NB) {   // column k + tc of L against x[k+NB:n]; rows ta, ta + NB, ... of it
+        const double* col = A + k + tc;
+        for (int r = k + NB + ta; r < n; r += 8 * NB) {
+          double rv[8];
+#pragma unroll
+          for (int u = 0; u < 8; ++u) rv[u] = col[(size_t)min(r + u * NB, n - 1) * ld];
+#pragma unroll
+          for (int u = 0; u < 8; u += 2) {
+            int r0 = r + u * NB, r1 = r0 + NB;
+            s0 += (r0 < n) ? rv[u] * bv(min(r0, n - 1)) : 0.0;
+            s1 += (r1 < n) ? rv[u + 1] * bv(min(r1, n - 1)) : 0.0;
+          }
+        }
+      }
+      if (!sweep) part[tc][ta] = s0 + s1;   // part[a][i]: partial a of solution entry i
+      else        part[ta][tc] = s0 + s1;
+      __syncthreads();
+      if (tid < 64) {   // lane i owns entry i of the block
+        const int lane = tid & (NB - 1);
+        double yi = (lane < nb) ? bv(k + lane) : 0.0, lr[NB];
+#pragma unroll
+        for (int q = 0; q < NB; ++q) yi -= part[q][lane];
+        if (!sweep) {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) lr[c] = l[lane][c];
+#pragma unroll
+          for (int c = 0; c < NB; ++c) {
+            double yc = readlane_f64(yi, c) * dinv[c];
+            yi = (lane == c) ? yc : ((lane > c) ? yi - lr[c] * yc : yi);
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < NB; ++c) lr[c] = l[c][lane];
+#pragma unroll
+          for (int c = NB - 1; c >= 0; --c) {
+            double yc = readlane_f64(yi, c) * dinv[c];
+            yi = (lane == c) ? yc : ((lane < c) ? yi - lr[c] * yc : yi);
+          }
+        }
+        if (tid < nb) bv(k + tid) = yi;
+      }
+      __syncthreads();
+    }
+  }
+  if (BL)
+    for (int i = tid; i < n; i += TRSV_T) b[i] = b_lds[i];
+}
+
+
+// ---------------------------------------------------------------- large matrices
+//
+// The driver's default for the source head is a dense solve whatever --solver says
+// (example.py:940-947); at BASELINE config 5 that is a 100 000 x 100 000 operator (80 GB), N^3/3 =
+// 333 TFLOP.  Right-looking blocked Cholesky with 256-wide panels:
+//   * the panel (all rows below, 256 columns) is factored by the 32-wide steps above, their
+//     updates capped at the panel's last column (HBM-bound, ~2 % of the time);
+//   * the rest of the matrix takes ONE rank-256 update per panel on the FP64 matrix cores,
+//     C -= P P^T over the lower-triangle tiles, P = the finished panel read in place.
+// chol_syrk_mfma_kernel: 128 x 128 tile per 4-wave workgroup (wave tile 64 x 64 = 16 accumulators
+// of v_mfma_f64_16x16x4_f64), two workgroups per CU so that one's prologue / epilogue / barriers
+// run under the other's matrix work.  K is walked in chunks of 16: both operand strips
+// (128 rows x 128 B each) are copied by LDS-DMA into one of two LDS stages one chunk ahead.
+// Lane (r = l & 15, g = l >> 4) of an MFMA needs P[row r][k = 4 step + g]: since the product sums
+// over k, any assignment of the chunk's 16 k-values to (step, g) works if both operands use the
+// same one -- lane group g reads the 16-byte pair (k = 2c, 2c+1), c = 4h + g, with ONE
+// ds_read_b128 and feeds steps 2h and 2h+1 from its halves.  A row is 128 B = 8 pairs; pair c of row
+// r sits at position c ^ ((r >> 1) & 7) (the per-lane DMA source address does the swizzle), which
+// makes every ds_read_b128 group hit 16 distinct 4-bank slots.
+// Algorithmic work: rest (rest + 128) * 256 flops per launch (rest = rows below the panel), bound:
+// FP64 MFMA; HBM traffic per tile: 128 KB of C in and out (32 flop/B) + the strips from L2.
+constexpr int PB = 256;           // panel width = K of one trailing update
+constexpr int CT = 128;           // output tile edge
+constexpr int KC = 16;            // k-values per LDS stage
+constexpr int NKC = PB / KC;
+constexpr int STG_BYTES = 2 * CT * KC * 8;   // one stage: A strip + B strip = 32 KiB
+constexpr int SUP = 8;            // tiles per edge of the patch one XCD works on at a time
+
+__device__ __forceinline__ void tri_of(int p, int* i, int* j) {   // p = i (i+1)/2 + j, j <= i
+  int a = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
+  while ((a + 1) * (a + 2) / 2 <= p) ++a;
+  while (a * (a + 1) / 2 > p) --a;
+  *i = a;
+  *j = p - a * (a + 1) / 2;
+}
+
+__device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
+  return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
+}
+
+__global__ void __launch_bounds__(256, 2)
+chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
+  __shared__ __align__(16) unsigned char smem[2 * STG_BYTES];
+  // block -> tile: blocks with equal id % 8 share an XCD (round-robin dispatch) and walk one
+  // 8 x 8 patch of tiles after another, so the ~64 tiles resident on an XCD share 16 row strips
+  const int id = blockIdx.x, slot = id >> 3;
+  const int sidx = (slot / (SUP * SUP)) * 8 + (id & 7);
+  if (sidx >= nsup) return;
+  int si, sj;
+  tri_of(sidx, &si, &sj);
+  const int within = slot % (SUP * SUP);
+  const int ti = si * SUP + within / SUP, tj = sj * SUP + within % SUP;
+  if (ti >= ntr || tj > ti) return;
+
+  const int t0 = k + PB;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, g = lane >> 4;
+  const int rowA0 = t0 + ti * CT, rowB0 = t0 + tj * CT;
+
+  // LDS-DMA: a stage is 32 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+4, ...:
+  // the first four belong to the A strip, the last four to the B strip.  Rows past the matrix
+  // are clamped (their products land in rows / columns that are not stored).
+  const char* baseA = reinterpret_cast<const char*>(A + (size_t)rowA0 * n + k);
+  const char* baseB = reinterpret_cast<const char*>(A + (size_t)rowB0 * n + k);
+  unsigned off[8];
+#pragma unroll
+  for (int i = 0; i < 8; ++i) {
+    const int q = wave + 4 * i;
+    const int pr = (q & 15) * 8 + (lane >> 3);
+    const int c = (lane & 7) ^ ((pr >> 1) & 7);
+    const int row0 = (i < 4) ? rowA0 : rowB0;
+    const int gr = min(row0 + pr, n - 1) - row0;
+    off[i] = (unsigned)gr * (unsigned)n * 8u + (unsigned)c * 16u;
+  }
+  auto issue = [&](int kc, int buf) {
+    unsigned char* dst = smem + buf * STG_BYTES + wave * 1024;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const char* src = ((i < 4) ? baseA : baseB) + off[i] + kc * (KC * 8);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(dst + i * 4096),
+                                       16, 0, 0);
+    }
+  };
+  issue(0, 0);
+
+  // accumulators start as -C (negation is exact; the sum of products is added, -acc stored)
+  f64x4 acc[4][4];
+  const int ci = rowA0 + wr * 64 + g, cj = rowB0 + wc * 64 + lr;
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int gi = min(ci + mi * 16 + 4 * e, n - 1), gj = min(cj + ni * 16, n - 1);
+        acc[mi][ni][e] = -A[(size_t)gi * n + gj];
+      }
+
+  const int swz = (lr >> 1) & 7;
+  const unsigned char* rdA = smem + (wr * 64 + lr) * (KC * 8);
+  const unsigned char* rdB = smem + CT * KC * 8 + (wc * 64 + lr) * (KC * 8);
+  const int p0 = ((0 + g) ^ swz) * 16, p1 = ((4 + g) ^ swz) * 16;
+
+  for (int kc = 0; kc < NKC; ++kc) {
+    const int buf = kc & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk kc have landed
+    __syncthreads();                                   // ... everyone's; stage buf^1 is free again
+    if (kc + 1 < NKC) issue(kc + 1, buf ^ 1);
+    const unsigned char* sa = rdA + buf * STG_BYTES;
+    const unsigned char* sb = rdB + buf * STG_BYTES;
+    f64x2 a0[4], a1[4], b0[4], b1[4];
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      a0[m] = *reinterpret_cast<const f64x2*>(sa + m * 16 * KC * 8 + p0);
+      b0[m] = *reinterpret_cast<const f64x2*>(sb + m * 16 * KC * 8 + p0);
+    }
+#pragma unroll
+    for (int m = 0; m < 4; ++m) {
+      a1[m] = *reinterpret_cast<const f64x2*>(sa + m * 16 * KC * 8 + p1);
+      b1[m] = *reinterpret_cast<const f64x2*>(sb + m * 16 * KC * 8 + p1);
+    }
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma64(a0[mi].x, b0[ni].x, acc[mi][ni]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma64(a0[mi].y, b0[ni].y, acc[mi][ni]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma64(a1[mi].x, b1[ni].x, acc[mi][ni]);
+#pragma unroll
+    for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+      for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma64(a1[mi].y, b1[ni].y, acc[mi][ni]);
+  }
+
+#pragma unroll
+  for (int mi = 0; mi < 4; ++mi)
+#pragma unroll
+    for (int ni = 0; ni < 4; ++ni)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        int gi = ci + mi * 16 + 4 * e, gj = cj + ni * 16;
+        if (gi < n && gj <= gi) A[(size_t)gi * n + gj] = -acc[mi][ni][e];
+      }
+}
+
+// Triangular solves for large n, one 256-wide panel at a time (right-looking both ways, so no
+// sum crosses workgroups): the diagonal block is solved by trsv_fused_kernel on that block, then
+//   forward : b[r] -= L[r, k:k+256] . y_k   for the rows r below the panel (one wave per row,
+//             4 columns per lane: a row of the panel is 2 KiB contiguous);
+//   backward: b[c] -= sum_r L[k+r, c] x_k[r] for the columns c left of the block (one thread per
+//             column, coalesced along the rows of L).
+// Both stream their part of L once: 4 n^2 bytes per sweep, HBM-bound.
+__global__ void __launch_bounds__(256)
+chol_fwd_update_kernel(const double* __restrict__ A, int n, int k, double* __restrict__ b) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const f64x2* yk = reinterpret_cast<const f64x2*>(b + k);
+  const f64x2 y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
+  const int r_begin = k + PB;
+  for (int r = r_begin + (blockIdx.x * 4 + wave) * 4; r < n; r += gridDim.x * 16) {
+    f64x2 v[4][2];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const f64x2* row = reinterpret_cast<const f64x2*>(A + (size_t)min(r + u, n - 1) * n + k);
+      v[u][0] = row[2 * lane];
+      v[u][1] = row[2 * lane + 1];
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      double s = (v[u][0].x * y0.x + v[u][0].y * y0.y) + (v[u][1].x * y1.x + v[u][1].y * y1.y);
+      s = wave_sum(s);
+      if (lane == 0 && r + u < n) b[r + u] -= s;
+    }
+  }
+}
+
+__global__ void __launch_bounds__(256)
+chol_bwd_update_kernel(const double* __restrict__ A, int n, int k, int nb, double* __restrict__ b) {
+  __shared__ double xk[PB];
+  for (int i = threadIdx.x; i < nb; i += 256) xk[i] = b[k + i];
+  __syncthreads();
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int cc = min(c, k - 1);
+  const double* col = A + (size_t)k * n + cc;
+  double s0 = 0.0, s1 = 0.0;
+  int r = 0;
+  for (; r + 8 <= nb; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + u) * n];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0 += v[u] * xk[r + u];
+      s1 += v[u + 1] * xk[r + u + 1];
+    }
+  }
+  for (; r < nb; ++r) s0 += col[(size_t)r * n] * xk[r];
+  if (c < k) b[c] -= s0 + s1;
+}
+}  // namespace hydra
+
+using namespace hydra;
+
+// Small matrices: below this the 32-wide path (a chain of ~4 n / 32 short launches) wins.
+static constexpr int CHOL_BLOCKED_MIN_N = 6144;
+
+static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_t s) {
+  dim3 tb(NB, NB);
+  potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, 0, info_dev);
+  for (int k = 0; k < n; k += NB) {
+    int nb = std::min(NB, n - k);
+    int rest = n - k - nb;
+    if (rest > 0) {   // then the block is full (nb == NB)
+      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, k);
+      int nblk = (rest + SY_T - 1) / SY_T;
+      syrk_update_kernel<<<dim3(nblk, nblk), 256, 0, s>>>(A, n, k, n, info_dev);  // + potrf of block k+NB
+    }
+  }
+  HYDRA_CHECK_LAUNCH("hydra_chol_solve(factor)");
+  size_t b_bytes = (size_t)n * sizeof(double);
+  int use_lds = b_bytes <= 96 * 1024;   // b rides in LDS when it fits beside the staging tiles
+  if (use_lds) {
+    int rc = reserve_lds(reinterpret_cast<const void*>(trsv_fused_kernel<true>), b_bytes);
+    if (rc) return rc;
+    trsv_fused_kernel<true><<<1, TRSV_T, b_bytes, s>>>(A, n, n, b, 0, 2);   // L y = b, then L^T x = y
+  } else {
+    trsv_fused_kernel<false><<<1, TRSV_T, 0, s>>>(A, n, n, b, 0, 2);
+  }
+  HYDRA_CHECK_LAUNCH("hydra_chol_solve(solve)");
+  return HYDRA_OK;
+}
+
+static int chol_factor_blocked(double* A, int n, int32_t* info_dev, hipStream_t s) {
+  dim3 tb(NB, NB);
+  for (int k = 0; k < n; k += PB) {
+    const int pb = std::min(PB, n - k), col_end = k + pb;
+    potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, k, info_dev);
+    for (int kk = k; kk < col_end; kk += NB) {
+      const int nb = std::min(NB, n - kk), rest = n - kk - nb;
+      if (rest <= 0) break;
+      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, kk);
+      const int ncols = col_end - (kk + NB);
+      if (ncols > 0)   // update the panel's remaining columns (+ potrf of the next 32-block)
+        syrk_update_kernel<<<dim3((ncols + SY_T - 1) / SY_T, (rest + SY_T - 1) / SY_T), 256, 0, s>>>(
+            A, n, kk, col_end, info_dev);
+    }
+    const int rest = n - col_end;
+    if (rest > 0) {   // then the panel is full (pb == PB)
+      const int ntr = (rest + CT - 1) / CT, nsr = (ntr + SUP - 1) / SUP;
+      const long long nsup = (long long)nsr * (nsr + 1) / 2;
+      const long long grid = (nsup + 7) / 8 * 8 * SUP * SUP;
+      if (grid > 2147483647LL) return fail(HYDRA_ERR_ARG, "hydra_chol_solve: n=%d is too large", n);
+      chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, s>>>(A, n, k, ntr, (int)nsup);
+    }
+  }
+  HYDRA_CHECK_LAUNCH("hydra_chol_solve(blocked factor)");
+  return HYDRA_OK;
+}
+
+static int chol_solve_blocked(const double* A, double* b, int n, hipStream_t s) {
+  const size_t lds = PB * sizeof(double);
+  for (int k = 0; k < n; k += PB) {            // L y = b
+    const int pb = std::min(PB, n - k);
+    trsv_fused_kernel<true><<<1, TRSV_T, lds, s>>>(A + (size_t)k * n + k, n, pb, b + k, 0, 1);
+    const int rest = n - k - pb;
+    if (rest > 0)
+      chol_fwd_update_kernel<<<std::min((rest + 15) / 16, 4096), 256, 0, s>>>(A, n, k, b);
+  }
+  for (int k = (n - 1) / PB * PB; k >= 0; k -= PB) {   // L^T x = y
+    const int pb = std::min(PB, n - k);
+    trsv_fused_kernel<true><<<1, TRSV_T, lds, s>>>(A + (size_t)k * n + k, n, pb, b + k, 1, 2);
+    if (k > 0) chol_bwd_update_kernel<<<(k + 255) / 256, 256, 0, s>>>(A, n, k, pb, b);
+  }
+  HYDRA_CHECK_LAUNCH("hydra_chol_solve(blocked solve)");
+  return HYDRA_OK;
+}
+
+extern "C" {
+
+int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream) {
+  HYDRA_CHECK_ARG(A && b && info_dev && n > 0, "hydra_chol_solve: bad arguments");
+  // (odd n: rows are not 16-byte aligned for the LDS-DMA of the blocked path -- callers pad, as
+  // hydra_amd.linear_solver.solve_dense does)
+  if (n >= CHOL_BLOCKED_MIN_N && n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(b) % 16 == 0)
+    return hydra_chol_solve_blocked(A, b, n, info_dev, stream);
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(info_dev, 0, sizeof(int32_t), s);
+  if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_chol_solve: %s", hipGetErrorString(e));
+  return chol_small(A, b, n, info_dev, s);
+}
+
+int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, void* stream) {
+  HYDRA_CHECK_ARG(A && info_dev && n > 0, "hydra_chol_solve_blocked: bad arguments");
+  HYDRA_CHECK_ARG(reinterpret_cast<uintptr_t>(A) % 16 == 0 && reinterpret_cast<uintptr_t>(b) % 16 == 0 &&
+                      n % 2 == 0,
+                  "hydra_chol_solve_blocked: A and b must be 16-byte aligned and n even (n=%d)", n);
+  hipStream_t s = as_stream(stream);
+  hipError_t e = hipMemsetAsync(info_dev, 0, sizeof(int32_t), s);
+  if (e != hipSuccess)
+    return fail(HYDRA_ERR_HIP, "hydra_chol_solve_blocked: %s", hipGetErrorString(e));
+  int rc = chol_factor_blocked(A, n, info_dev, s);
+  if (rc || !b) return rc;
+  return chol_solve_blocked(A, b, n, s);
+}
+
+}  // extern "C"

@@ -416,290 +416,6 @@ cgl_dir_kernel(int n, const double* __restrict__ r, double* __restrict__ p,
   }
 }
 
-// ---------------------------------------------------------------- blocked Cholesky
-
-constexpr int NB = 32;
-
-__device__ __forceinline__ double readlane_f64(double x, int lane) {
-  int lo = __builtin_amdgcn_readlane(__double2loint(x), lane);
-  int hi = __builtin_amdgcn_readlane(__double2hiint(x), lane);
-  return __hiloint2double(hi, lo);
-}
-
-// Cholesky of one NB x NB block by ONE wave, rows in registers: lane i (< NB) holds row i of the
-// lower triangle in v[]; column c's pivot and multipliers travel by v_readlane, so the NB steps
-// need no LDS and no barrier (the barrier-per-column form took 16 us per block, this one ~2).
-// Entries above the diagonal are never read.  Returns true if a pivot was not positive.
-__device__ __forceinline__ bool potrf_wave(double (&v)[NB], int i) {
-  bool bad = false;
-#pragma unroll
-  for (int c = 0; c < NB; ++c) {
-    double d = readlane_f64(v[c], c);
-    if (!(d > 0.0)) bad = true;
-    // reciprocal square root + one correction instead of sqrt and a divide per column: the two
-    // long dependent sequences were most of this routine's time
-    double inv = rsqrt(d);
-    double sd = d * inv;
-    sd = fma(fma(-sd, sd, d), 0.5 * inv, sd);
-    v[c] = (i == c) ? sd : v[c] * inv;
-#pragma unroll
-    for (int j = c + 1; j < NB; ++j) {
-      double ljc = readlane_f64(v[c], j);
-      v[j] -= v[c] * ljc;
-    }
-  }
-  return bad;
-}
-
-// factor the nb x nb diagonal block at (k,k) in place from the tile `t` in LDS (rows/cols >= nb
-// are treated as identity); called by the first wave of a workgroup.
-__device__ __forceinline__ void potrf_tile(const double (*t)[NB + 1], double* __restrict__ A, int n,
-                                           int k, int nb, int32_t* __restrict__ info, int lane) {
-  int i = lane & (NB - 1);
-  double v[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) v[j] = (i < nb && j < nb) ? t[i][j] : (i == j ? 1.0 : 0.0);
-  bool bad = potrf_wave(v, i);
-  if (bad && lane == 0) atomicOr(info, 1);
-  if (lane < nb) {
-    double* row = A + (size_t)(k + lane) * n + k;
-#pragma unroll
-    for (int j = 0; j < NB; ++j)
-      if (j <= lane) row[j] = v[j];
-  }
-}
-
-// first diagonal block (the later ones are factored by the trailing update that completes them)
-__global__ void __launch_bounds__(NB * NB)
-potrf_diag_kernel(double* __restrict__ A, int n, int k, int32_t* __restrict__ info) {
-  __shared__ double s[NB][NB + 1];
-  int i = threadIdx.y, j = threadIdx.x;
-  int nb = min(NB, n - k);
-  s[i][j] = (i < nb && j < nb) ? A[(size_t)(k + i) * n + k + j] : (i == j ? 1.0 : 0.0);
-  __syncthreads();
-  int tid = i * NB + j;
-  if (tid < 64) potrf_tile(s, A, n, k, nb, info, tid);
-}
-
-// rows below a full diagonal block: A[r, k:k+NB] <- A[r, k:k+NB] L11^-T, thread <-> row.  One wave
-// per workgroup so the panel spreads over many CUs (the substitution reads L11 from LDS once per
-// multiply-add); rows travel through LDS so that global accesses run along the rows.
-constexpr int TRSM_T = 64;
-static_assert(TRSM_T == 2 * NB, "trsm staging assumes two rows per trip");
-__global__ void __launch_bounds__(TRSM_T)
-trsm_panel_kernel(double* __restrict__ A, int n, int k) {
-  __shared__ double l[NB][NB + 1];
-  __shared__ double dinv[NB];
-  __shared__ double rows[TRSM_T][NB + 1];
-  const int tid = threadIdx.x;
-  // unconditional loads (in bounds: the block is full, row indices are clamped) so that the
-  // compiler can issue them all before the first use
-  const int r0 = k + NB + blockIdx.x * TRSM_T;
-  {
-    const int j = tid % NB, i0 = tid / NB;   // TRSM_T / NB = 2 rows per trip
-    double a[NB / 2], rr[NB];
-#pragma unroll
-    for (int q = 0; q < NB / 2; ++q) a[q] = A[(size_t)(k + i0 + 2 * q) * n + k + j];
-#pragma unroll
-    for (int q = 0; q < NB; ++q) rr[q] = A[(size_t)min(r0 + i0 + 2 * q, n - 1) * n + k + j];
-#pragma unroll
-    for (int q = 0; q < NB / 2; ++q) {
-      int i = i0 + 2 * q;
-      l[i][j] = (j <= i) ? a[q] : 0.0;
-      if (i == j) dinv[i] = 1.0 / a[q];
-    }
-#pragma unroll
-    for (int q = 0; q < NB; ++q) rows[i0 + 2 * q][j] = rr[q];
-  }
-  __syncthreads();
-  double v[NB];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) v[j] = rows[tid][j];
-#pragma unroll
-  for (int j = 0; j < NB; ++j) {
-    double t = v[j];
-#pragma unroll
-    for (int c = 0; c < j; ++c) t -= v[c] * l[j][c];
-    v[j] = t * dinv[j];
-  }
-#pragma unroll
-  for (int j = 0; j < NB; ++j) rows[tid][j] = v[j];
-  __syncthreads();
-#pragma unroll
-  for (int q = 0; q < NB; ++q) {
-    int i = tid / NB + 2 * q, j = tid % NB;
-    if (r0 + i < n) A[(size_t)(r0 + i) * n + k + j] = rows[i][j];
-  }
-}
-
-// trailing update of the lower triangle: A22 -= L21 L21^T, 64x64 output tiles by 256 threads
-// (4x4 entries each, the NB-deep panels in LDS).  The top-left NB x NB corner of tile (0,0) is the
-// NEXT diagonal block, complete after this update: its workgroup factors it on the spot, which
-// saves one launch per block column.  Only launched for full blocks (nb == NB).
-constexpr int SY_T = 64;
-__global__ void __launch_bounds__(256)
-syrk_update_kernel(double* __restrict__ A, int n, int k, int32_t* __restrict__ info) {
-  const int base = k + NB;
-  const int bi = blockIdx.y, bj = blockIdx.x;
-  if (bj > bi) return;
-  __shared__ double sa[SY_T][NB + 1], sb[SY_T][NB + 1];
-  const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
-  const int i0 = base + bi * SY_T, j0 = base + bj * SY_T;
-  {
-    const int c = tid % NB, r = tid / NB;   // 8 panel rows per trip, loads along the rows
-    double pa[SY_T / 8], pb[SY_T / 8];
-#pragma unroll
-    for (int q = 0; q < SY_T / 8; ++q) {
-      pa[q] = A[(size_t)min(i0 + r + 8 * q, n - 1) * n + k + c];
-      pb[q] = A[(size_t)min(j0 + r + 8 * q, n - 1) * n + k + c];
-    }
-#pragma unroll
-    for (int q = 0; q < SY_T / 8; ++q) {
-      sa[r + 8 * q][c] = pa[q];
-      sb[r + 8 * q][c] = pb[q];
-    }
-  }
-  double old[4][4];
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
-      old[a][b] = (gi < n && gj <= gi) ? A[(size_t)gi * n + gj] : 0.0;
-    }
-  __syncthreads();
-  double acc[4][4] = {};
-#pragma unroll 8
-  for (int c = 0; c < NB; ++c) {
-    double ra[4], rb[4];
-#pragma unroll
-    for (int a = 0; a < 4; ++a) ra[a] = sa[ty + 16 * a][c];
-#pragma unroll
-    for (int b = 0; b < 4; ++b) rb[b] = sb[tx + 16 * b][c];
-#pragma unroll
-    for (int a = 0; a < 4; ++a)
-#pragma unroll
-      for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
-  }
-  const bool corner = bi == 0;   // then bj == 0 too: this tile holds the next diagonal block
-  if (corner) __syncthreads();   // sa is free: its first NB rows take the updated corner
-#pragma unroll
-  for (int a = 0; a < 4; ++a)
-#pragma unroll
-    for (int b = 0; b < 4; ++b) {
-      int li = ty + 16 * a, lj = tx + 16 * b;
-      int gi = i0 + li, gj = j0 + lj;
-      double val = old[a][b] - acc[a][b];
-      if (corner && li < NB && lj < NB) sa[li][lj] = val;
-      else if (gi < n && gj <= gi) A[(size_t)gi * n + gj] = val;
-    }
-  if (!corner) return;
-  __syncthreads();
-  if (tid < 64) potrf_tile(sa, A, n, base, min(NB, n - base), info, tid);
-}
-
-// Both triangular solves of the Cholesky fallback in ONE launch by one workgroup of NB*NB threads
-// (a kernel pair per block column needs 4 n / NB launches of 5-18 us each, most of the solve time
-// at n ~ 2000).  Left-looking: block k of the solution needs sum_j L[k, j] y_j over the blocks
-// already solved, a (NB x k) product whose loads run along the rows of L (forward sweep) or along
-// the NB-wide column panel (backward sweep) - 256-byte pieces either way, never one line per lane.
-// Thread (a, c) = (tid / NB, tid % NB) leaves a partial sum in part[][]; the first wave adds them
-// up and does the NB x NB substitution in registers.  L is read once per sweep.
-constexpr int TRSV_T = NB * NB;
-
-// element (tid / NB, tid % NB) of the diagonal block at (k,k), clamped into the matrix (entries
-// outside the nb x nb lower triangle are masked when staged)
-__device__ __forceinline__ double trsv_diag_load(const double* __restrict__ A, int n, int k, int tid) {
-  int i = min(max(k, 0) + tid / NB, n - 1), j = min(max(k, 0) + tid % NB, n - 1);
-  return A[(size_t)i * n + j];
-}
-
-// BL: the solution vector lives in dynamic LDS (copied in and out), next to the multiply-adds;
-// otherwise it stays in b.  (A template, not a flat pointer: flat loads wait on both memory
-// counters and would serialise against the loads of L.)
-template <bool BL>
-__global__ void __launch_bounds__(TRSV_T)
-trsv_fused_kernel(const double* __restrict__ A, int n, double* __restrict__ b) {
-  extern __shared__ double b_lds[];
-  __shared__ double l[NB][NB + 1];
-  __shared__ double part[NB][NB + 1];
-  __shared__ double dinv[NB];
-  const int tid = threadIdx.x;
-  const int ta = tid / NB, tc = tid % NB;
-  if (BL)
-    for (int i = tid; i < n; i += TRSV_T) b_lds[i] = b[i];
-  auto bv = [&](int i) -> double& { return BL ? b_lds[i] : b[i]; };
-  __syncthreads();
-  const int last = ((n - 1) / NB) * NB;
-  for (int sweep = 0; sweep < 2; ++sweep) {   // 0: L y = b left to right, 1: L^T x = y right to left
-    double a = trsv_diag_load(A, n, sweep ? last : 0, tid);
-    for (int k = sweep ? last : 0; sweep ? k >= 0 : k < n; k += sweep ? -NB : NB) {
-      const int nb = min(NB, n - k);
-      l[ta][tc] = (ta < nb && tc <= ta) ? a : 0.0;
-      if (ta == tc) dinv[ta] = (ta < nb) ? 1.0 / a : 1.0;
-      a = trsv_diag_load(A, n, sweep ? k - NB : k + NB, tid);   // next block, in flight meanwhile
-      double s0 = 0.0, s1 = 0.0;
-      if (!sweep) {   // row k + ta of L against y[0:k]; this thread takes columns tc, tc + NB, ...
-        const double* row = A + (size_t)min(k + ta, n - 1) * n;
-        for (int j = tc; j < k; j += 8 * NB) {   // 8 loads in flight; the tail is masked, not serial
-          double rv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) rv[u] = row[min(j + u * NB, k - NB + tc)];
-#pragma unroll
-          for (int u = 0; u < 8; u += 2) {
-            int j0 = j + u * NB, j1 = j0 + NB;
-            s0 += (j0 < k) ? rv[u] * bv(min(j0, k - 1)) : 0.0;
-            s1 += (j1 < k) ? rv[u + 1] * bv(min(j1, k - 1)) : 0.0;
-          }
-        }
-      } else if (nb == NB) {   // column k + tc of L against x[k+NB:n]; rows ta, ta + NB, ... of it
-        const double* col = A + k + tc;
-        for (int r = k + NB + ta; r < n; r += 8 * NB) {
-          double rv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) rv[u] = col[(size_t)min(r + u * NB, n - 1) * n];
-#pragma unroll
-          for (int u = 0; u < 8; u += 2) {
-            int r0 = r + u * NB, r1 = r0 + NB;
-            s0 += (r0 < n) ? rv[u] * bv(min(r0, n - 1)) : 0.0;
-            s1 += (r1 < n) ? rv[u + 1] * bv(min(r1, n - 1)) : 0.0;
-          }
-        }
-      }
-      if (!sweep) part[tc][ta] = s0 + s1;   // part[a][i]: partial a of solution entry i
-      else        part[ta][tc] = s0 + s1;
-      __syncthreads();
-      if (tid < 64) {   // lane i owns entry i of the block
-        const int lane = tid & (NB - 1);
-        double yi = (lane < nb) ? bv(k + lane) : 0.0, lr[NB];
-#pragma unroll
-        for (int q = 0; q < NB; ++q) yi -= part[q][lane];
-        if (!sweep) {
-#pragma unroll
-          for (int c = 0; c < NB; ++c) lr[c] = l[lane][c];
-#pragma unroll
-          for (int c = 0; c < NB; ++c) {
-            double yc = readlane_f64(yi, c) * dinv[c];
-            yi = (lane == c) ? yc : ((lane > c) ? yi - lr[c] * yc : yi);
-          }
-        } else {
-#pragma unroll
-          for (int c = 0; c < NB; ++c) lr[c] = l[c][lane];
-#pragma unroll
-          for (int c = NB - 1; c >= 0; --c) {
-            double yc = readlane_f64(yi, c) * dinv[c];
-            yi = (lane == c) ? yc : ((lane < c) ? yi - lr[c] * yc : yi);
-          }
-        }
-        if (tid < nb) bv(k + tid) = yi;
-      }
-      __syncthreads();
-    }
-  }
-  if (BL)
-    for (int i = tid; i < n; i += TRSV_T) b[i] = b_lds[i];
-}
-
 }  // namespace hydra
 
 using namespace hydra;
@@ -875,38 +591,6 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
     it += chunk;
   }
   if (iters_host) *iters_host = (int)st_host[2];
-  return HYDRA_OK;
-}
-
-int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream) {
-  HYDRA_CHECK_ARG(A && b && info_dev && n > 0, "hydra_chol_solve: bad arguments");
-  hipStream_t s = as_stream(stream);
-  hipError_t e = hipMemsetAsync(info_dev, 0, sizeof(int32_t), s);
-  if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_chol_solve: %s", hipGetErrorString(e));
-  dim3 tb(NB, NB);
-  potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, 0, info_dev);
-  for (int k = 0; k < n; k += NB) {
-    int nb = std::min(NB, n - k);
-    int rest = n - k - nb;
-    if (rest > 0) {   // then the block is full (nb == NB)
-      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, k);
-      int nblk = (rest + SY_T - 1) / SY_T;
-      syrk_update_kernel<<<dim3(nblk, nblk), 256, 0, s>>>(A, n, k, info_dev);  // + potrf of block k+NB
-    }
-  }
-  HYDRA_CHECK_LAUNCH("hydra_chol_solve(factor)");
-  {
-    size_t b_bytes = (size_t)n * sizeof(double);
-    int use_lds = b_bytes <= 96 * 1024;   // b rides in LDS when it fits beside the staging tiles
-    if (use_lds) {
-      int rc = reserve_lds(reinterpret_cast<const void*>(trsv_fused_kernel<true>), b_bytes);
-      if (rc) return rc;
-      trsv_fused_kernel<true><<<1, TRSV_T, b_bytes, s>>>(A, n, b);   // L y = b, then L^T x = y
-    } else {
-      trsv_fused_kernel<false><<<1, TRSV_T, 0, s>>>(A, n, b);
-    }
-  }
-  HYDRA_CHECK_LAUNCH("hydra_chol_solve(solve)");
   return HYDRA_OK;
 }
 

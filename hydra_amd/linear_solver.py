@@ -95,14 +95,32 @@ def cg(Amat, bvec, maxiters=1000, abs_tol=1e-8, use_norm_tol=False, x0=None, lin
     return (out, iters) if return_iters else out
 
 
-def solve_dense(Amat, bvec):
+BLOCKED_MIN_N = 6144     # hydra_chol_solve switches to 256-wide panels + MFMA updates from here
+
+
+def solve_dense(Amat, bvec, overwrite_a=False):
     """Dense fallback: ``scipy.linalg.solve(A, b, assume_a='her')`` of the driver
     (example.py:944) for the symmetric positive-definite GCR operator, by blocked Cholesky
-    on the GPU.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
-    A = _dev.f64(Amat).clone()
+    on the GPU (csrc/chol.hip; from 6144 unknowns on: 256-wide panels with the trailing update on
+    the FP64 matrix cores -- the 100 000-source operator of config 5 is an 80 GB matrix).
+    ``overwrite_a=True`` (GPU tensor input only) factors in place instead of on a copy.
+    Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
+    A = _dev.f64(Amat)
     b = _dev.f64(bvec).clone()
     n = b.numel()
     assert tuple(A.shape) == (n, n)
+    if n >= BLOCKED_MIN_N and n % 2 == 1:
+        # the large-matrix path moves rows by 16-byte LDS-DMA: pad to even n with a unit pivot
+        Ap = torch.empty((n + 1, n + 1), dtype=torch.float64, device=A.device)
+        Ap[:n, :n] = A
+        Ap[n, :] = 0.0
+        Ap[:n, n] = 0.0
+        Ap[n, n] = 1.0
+        bp = torch.zeros(n + 1, dtype=torch.float64, device=A.device)
+        bp[:n] = b
+        return _dev.like(bvec, solve_dense(Ap, bp, overwrite_a=True)[:n].clone())
+    if not (overwrite_a and A is Amat):
+        A = A.clone()
     info = _dev.zeros((1,), torch.int32)
     _dev.call("hydra_chol_solve", _dev.ptr(A), _dev.ptr(b), n, _dev.ptr(info), _dev.stream_ptr())
     if int(info.item()) != 0:

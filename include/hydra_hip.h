@@ -318,6 +318,16 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
  * by its factor; b by x.  Returns 1 if A is not positive definite.                       */
 int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream);
 
+/* The large-matrix algorithm behind hydra_chol_solve (taken automatically for even n >= 6144):
+ * 256-wide panels factored by 32-wide steps, then ONE rank-256 update of the rest of the lower
+ * triangle per panel on the FP64 matrix cores (C -= P P^T, P = the finished panel read in place),
+ * and panel-wise multi-workgroup triangular solves.  N^3/3 flops, FP64-MFMA-bound: the 100 000-source
+ * operator of BASELINE config 5 (80 GB) is the case it exists for -- the reference's driver solves
+ * the source head densely whatever --solver says (example.py:940-947).  A (N,N) f64, 16-byte
+ * aligned, N even; the lower triangle is overwritten by L (the strict upper triangle is left
+ * stale).  b == NULL: factor only.  *info_dev = 1 if A is not positive definite.              */
+int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, void* stream);
+
 /* ---- spherical-harmonic response (simulate_vis_per_alm) -------------------------- */
 
 /* RING pixel centres: theta, phi (Npix = 12 nside^2)                vis_simulator.py:659 */
