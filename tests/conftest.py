@@ -31,3 +31,17 @@ def relerr(a, b):
     if denom == 0:
         return float(np.max(np.abs(a - b)))
     return float(np.max(np.abs(a - b)) / denom)
+
+
+def elem_err(a, b, rtol=1e-10, floor=1e-13):
+    """Element-wise parity measure: max over entries of |a-b| / (rtol |b| + floor max|b|).
+    <= 1 means every entry agrees to ``rtol`` relative, except entries smaller than
+    floor/rtol of the largest one, which must agree to ``floor`` of the largest (a sum of
+    thousands of terms cannot do better than its own rounding).  ``relerr`` alone is a max-norm
+    test: a source 1e-6 of the brightest could be wrong at 1e-4 and pass it."""
+    a = np.asarray(a)
+    b = np.asarray(b)
+    scale = float(np.max(np.abs(b))) if b.size else 0.0
+    if scale == 0.0:
+        return float(np.max(np.abs(a))) if a.size else 0.0
+    return float(np.max(np.abs(a - b) / (rtol * np.abs(b) + floor * scale)))
