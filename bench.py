@@ -47,8 +47,9 @@ CONFIGS = {
     "c5s": ((11, 21), 8192, 8, 1),
     # c5 = BASELINE config 5 at full source count on ONE GPU's share of the channels: 350 antennas,
     # 100 000 sources (80 GB Gram), gridded beam; 2 channels x 1 time per step here (the node
-    # target is 128 channels over 8 GPUs = 16 per GPU); CG solve (a dense factorisation of a
-    # 100 000^2 matrix is not what the reference would do either: example.py --solver mpicg)
+    # target is 128 channels over 8 GPUs = 16 per GPU); solved densely as the reference's driver
+    # does whatever --solver says (example.py:940-947): 256-wide-panel Cholesky on the matrix
+    # cores (csrc/chol.hip); --solver cg gives the reference's unpreconditioned CG instead
     "c5": ((11, 21), 100000, 2, 1),
 }
 SH_CONFIGS = {
@@ -126,15 +127,26 @@ def pmc_traffic(config, kernel=None):
         return None
 
 
-def cpu_baseline(inp, nf_s, nt_s, full_rows):
-    """Time the oracle (numpy/scipy restatement of the reference) on an (nf_s x nt_s) slice of
-    the workload and scale linearly in the number of visibility rows."""
-    from oracle import beams as obeams, gcr_ptsrc, helpers
+def _blas_threads():
     try:
         from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
+        return max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
     except Exception:
-        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+        return int(os.environ.get("OMP_NUM_THREADS", "1"))
+
+
+def cpu_baseline(inp, nf_s, nt_s, full_rows, single_thread=False):
+    """Time the oracle (numpy/scipy restatement of the reference) on an (nf_s x nt_s) slice of
+    the workload and scale linearly in the number of visibility rows.  ``single_thread`` runs
+    the same slice with the BLAS pool limited to one thread (SURVEY 8(d) asks for both)."""
+    if single_thread:
+        from threadpoolctl import threadpool_limits
+        with threadpool_limits(limits=1):
+            out = cpu_baseline(inp, nf_s, nt_s, full_rows)
+        out["cores"] = 1
+        return out
+    from oracle import beams as obeams, gcr_ptsrc, helpers
+    threads = _blas_threads()
     ant_pos, antpairs = inp["ant_pos"], inp["antpairs"]
     nant, nbl, ns = len(ant_pos), len(antpairs), inp["ra"].size
     freqs, times = inp["freqs"][:nf_s], inp["times"][:nt_s]
@@ -173,12 +185,8 @@ def sh_cpu_baseline(rows, full_rows, nm):
     """The oracle's SH head (numpy restatement of sh_sampler.construct_rhs_no_rot + cg with the
     reference's per-iteration apply_lhs_no_rot) on ``rows`` visibility rows, scaled linearly in
     rows; the reference forms the (Nm,Nm) Gram inside EVERY CG iteration (sh_sampler.py:393-398)."""
-    from oracle import beams as obeams, cg as ocg, gcr_sh
-    try:
-        from threadpoolctl import threadpool_info
-        threads = max([p.get("num_threads", 1) for p in threadpool_info()] or [1])
-    except Exception:
-        threads = int(os.environ.get("OMP_NUM_THREADS", "1"))
+    from oracle import gcr_sh
+    threads = _blas_threads()
     # a random operator of the right shape stands in for the response (building the real one on
     # the CPU takes minutes and is not part of a sample); the arithmetic timed is identical
     rng = np.random.RandomState(0)
@@ -333,6 +341,40 @@ def main_sh(args, comm, rank, world, dev):
     print(json.dumps(out))
 
 
+def gain_cpu_baseline(ants, antpairs, Fb_all, nf, nt, iters, seed=0):
+    """The oracle's gain head (numpy restatement of gain_sampler.construct_rhs_mpi and
+    apply_operator_mpi) on a 2 x 8 (freq x time) slice of the workload; both are sums over
+    (f,t) samples of per-sample work, so the time is scaled linearly in Nf*Nt.  One sample =
+    one right-hand side + ``iters`` operator applications (the CG of the driver)."""
+    from oracle import gcr_gain
+    nf_s, nt_s = min(nf, 2), min(nt, 8)
+    nant, nbl = len(ants), len(antpairs)
+    i1, i2 = gcr_gain.bl_indices(ants, antpairs)
+    rng = np.random.RandomState(seed)
+    Fb = np.ascontiguousarray(Fb_all[:, :nf_s, :nt_s])
+    nmodes = Fb.shape[0]
+    shape = (nbl, nf_s, nt_s)
+    mv = rng.randn(*shape) + 1j * rng.randn(*shape)
+    w = np.full(shape, 400.0)
+    ps = np.full(nmodes, 0.05)
+    x = rng.randn(2 * nant * nmodes)
+    om_y, om_r = gcr_gain.draw_gain_omegas(1, nant, nmodes, shape)
+    t0 = time.perf_counter()
+    gcr_gain.construct_rhs(mv, w, ps, i1, i2, mv, Fb, om_y, om_r)
+    t_rhs = time.perf_counter() - t0
+    t0 = time.perf_counter()
+    for _ in range(2):
+        gcr_gain.apply_operator(x, w, ps, i1, i2, mv, Fb)
+    t_op = (time.perf_counter() - t0) / 2
+    scale = (nf * nt) / (nf_s * nt_s)
+    total = scale * (t_rhs + max(int(iters), 1) * t_op)
+    return {"value": 1.0 / total, "unit": "samples/s", "cores": _blas_threads(), "kind": "port",
+            "sample": (f"oracle (numpy restatement of gain_sampler.construct_rhs_mpi + apply_operator_mpi) "
+                       f"on a {nf_s}x{nt_s} of {nf}x{nt} (freq x time) slice, all {nbl} baselines: rhs "
+                       f"{t_rhs:.2f}s + {int(iters)} CG operator applications x {t_op:.2f}s, scaled "
+                       f"linearly in Nf*Nt")}
+
+
 def main_gain(args, comm, rank, world, dev):
     """GCR samples/s of the linearised gain head (example.py:673-745): per sample the residual
     d - g g* V, the right-hand side (gain_sampler.construct_rhs_mpi) and a CG solve of
@@ -469,6 +511,8 @@ def main_gain(args, comm, rank, world, dev):
         },
         "cpu_baseline": None,
     }
+    if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
+        out["cpu_baseline"] = gain_cpu_baseline(ants, antpairs, Fb_all, nf, nt, iters)
     print(json.dumps(out))
 
 
@@ -759,9 +803,11 @@ def main():
                     help="auto = closed-form antenna-space Gram when the array is complete and the "
                          "noise weights do not depend on the baseline (true for this workload), "
                          "general = always the per-baseline-weight kernel")
+    ap.add_argument("--no-general", action="store_true",
+                    help="skip the extra launches of the general Gram kernel after the timed region")
     ap.add_argument("--shard", default=None, choices=["freq", "baseline"],
                     help="how the visibility rows are split over GPUs (default: freq; c5s: baseline)")
-    ap.add_argument("--solver", default="dense", choices=["dense", "cg", "cg-rows"],
+    ap.add_argument("--solver", default=None, choices=["dense", "cg", "cg-rows"],
                     help="dense = blocked Cholesky (the reference's default for this head, "
                          "example.py:944); cg = linear_solver.cg on the root; cg-rows = the operator "
                          "stays sharded by rows over the GPUs and every rank runs the CG with a "
@@ -791,10 +837,11 @@ def main():
     hex_spec, ns, nf, nt = CONFIGS[args.config]
     big = args.config in ("c5s", "c5")
     shard = args.shard or ("baseline" if args.config == "c5s" else "freq")
+    if args.solver is None:
+        # one GPU factors the operator (config 5: 80 GB, 5.7 s); with more GPUs config 5 keeps the
+        # summed Gram sharded by rows and every rank runs the CG on its rows
+        args.solver = "cg-rows" if (args.config == "c5" and world > 1) else "dense"
     if args.config == "c5":
-        # one GPU multiplies the 80 GB operator alone (7 ms per product); with more, each keeps its
-        # rows of the summed Gram and multiplies those
-        args.solver = "cg-rows" if world > 1 else "cg"
         args.no_cpu = True     # the CPU path cannot form or solve a 100 000^2 system in minutes
     if args.solver == "cg-rows" and world == 1:
         args.solver = "cg"
@@ -862,7 +909,18 @@ def main():
             x, iters = hy.linear_solver.cg(A, b, maxiters=1000, abs_tol=args.cg_tol,
                                            return_iters=True)
         elif rank == 0:
-            x, iters = hy.linear_solver.solve_dense(A, b), 0
+            # A is rebuilt every sample, so the factorisation may overwrite it (no 80 GB copy);
+            # keep what the residual check below needs
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            keep_A = A if ns <= 20000 else None
+            ev[0].record()
+            x = hy.linear_solver.solve_dense(A.clone() if keep_A is not None else A, b,
+                                             overwrite_a=True)
+            ev[1].record()
+            solve_events.append(ev)
+            iters = 0
+            if keep_A is None:
+                A = None
         else:
             x, iters = torch.zeros(ns, dtype=torch.float64, device=dev), 0
         if comm is not None:
@@ -874,9 +932,11 @@ def main():
             comm.barrier()
         torch.cuda.synchronize()
 
+    solve_events = []
     for _ in range(args.warmup):
         one_sample()
     ptsrc_sampler.GRAM_EVENTS = []
+    solve_events.clear()
     sync()
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -890,12 +950,20 @@ def main():
         comm.allreduce_(t_all, op="max")
     elapsed = float(t_all.item())
     gram_ms = float(np.mean([s.elapsed_time(e) for s, e in events])) if events else float("nan")
+    solve_ms = float(np.mean([s.elapsed_time(e) for s, e in solve_events])) if solve_events \
+        else float("nan")
 
-    # sanity of the last sample (outside the timed region; the row-sharded product is collective)
+    # sanity of the last sample (outside the timed region; the row-sharded product is collective).
+    # The in-place factorisation of the 80 GB operator consumed it: rebuild it from the same
+    # inputs (same Gram; b and x belong to the last sample's fluctuation draws, which only enter b)
+    if A is None and rank == 0:
+        A, _ = ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs_loc, times, fac, data,
+                                            inv_noise, gains, prior, realisation=False)
     Ax = A(x) if args.solver == "cg-rows" else (A @ x if rank == 0 else None)
     if rank != 0:
         return
     resid = float((torch.linalg.norm(Ax - b) / torch.linalg.norm(b)).item())
+    del Ax
     # Algorithmic flops per launch of the kernel that ran (this rank's rows):
     #   gram_fused_kernel   (baseline form):  2 M Ns (Ns+1)                  [SURVEY 8(d)]
     #   gram_uniform_kernel (antenna form, 3-product complex multiply):
@@ -911,6 +979,40 @@ def main():
         gram_flops = baseline_form_flops
     achieved = gram_flops / (gram_ms * 1e-3) / 1e12
     effective = baseline_form_flops / (gram_ms * 1e-3) / 1e12
+    roof_ran = {
+        "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
+        "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
+        "traffic": pmc_traffic(args.config, kernel) if world == 1 else None,
+        "kernel": kernel, "ms_per_launch": gram_ms, "flops_per_launch": gram_flops,
+    }
+    # SURVEY 8(d) defines the Gram rate on the baseline-form count 2 M Ns (Ns+1), which is what
+    # gram_fused_kernel executes.  When the sample above took the closed form, time the general
+    # kernel on the same inputs in this same run (a few launches, outside `value`) and make THAT
+    # the roofline entry; the closed-form figures move to roofline_closed_form.
+    roof_general, agree = None, None
+    if kernel == "gram_uniform_kernel" and world == 1 and not big and not args.no_general:
+        A_auto = fac.gram(gains, inv_noise, prior_std=prior)
+        fac.allow_uniform = False
+        ptsrc_sampler.GRAM_EVENTS = []
+        for _ in range(2):
+            A_gen = ptsrc_sampler._timed_gram(lambda: fac.gram(gains, inv_noise, prior_std=prior))
+        torch.cuda.synchronize()
+        gen_ms = float(np.mean([s_.elapsed_time(e_) for s_, e_ in ptsrc_sampler.GRAM_EVENTS]))
+        ptsrc_sampler.GRAM_EVENTS = None
+        fac.allow_uniform = True
+        agree = float(((A_auto - A_gen).abs().max() / A_gen.abs().max()).item())
+        del A_auto, A_gen
+        g_ach = baseline_form_flops / (gen_ms * 1e-3) / 1e12
+        roof_general = {
+            "bound": "mfma", "achieved": g_ach, "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s",
+            "frac": g_ach / FP64_MATRIX_PEAK_TFLOPS,
+            "traffic": pmc_traffic(args.config, "gram_fused_kernel"),
+            "kernel": "gram_fused_kernel", "ms_per_launch": gen_ms,
+            "flops_per_launch": baseline_form_flops,
+            "note": ("SURVEY 8(d) Gram: per-baseline-weight kernel, 2 M Ns (Ns+1) flops, timed on "
+                     "this run's inputs outside `value`; `value` uses the closed-form kernel "
+                     "(roofline_closed_form), which forms the same matrix with fewer operations"),
+        }
     out = {
         "metric": "GCR samples/sec (ptsrc head, whole job)",
         "value": args.steps / elapsed,
@@ -938,20 +1040,32 @@ def main():
         # fewer operations)
         "gram_tflops_whole_job": world * effective,
         "sample_rel_residual": resid,
-        "roofline": {
-            "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
-            "unit": "TFLOP/s", "frac": achieved / FP64_MATRIX_PEAK_TFLOPS,
-            "traffic": pmc_traffic(args.config, kernel) if world == 1 else None,
-            "kernel": kernel, "ms_per_launch": gram_ms,
-            "flops_per_launch": gram_flops,
-        },
+        "roofline": roof_general if roof_general is not None else roof_ran,
     }
+    if roof_general is not None:
+        out["roofline_closed_form"] = roof_ran
+        out["general_vs_closed_form_relerr"] = agree
+    if solve_events:
+        fl = ns ** 3 / 3.0
+        s_ach = fl / (solve_ms * 1e-3) / 1e12
+        out["dense_solve"] = {
+            "kernel": ("chol_syrk_mfma_kernel (256-wide-panel Cholesky, trailing update on the FP64 "
+                       "matrix cores) + panel steps + triangular solves" if ns >= 6144 else
+                       "32-wide blocked Cholesky (launch-chain bound at this size)"),
+            "n": ns, "ms": solve_ms, "flops": fl, "bound": "mfma", "achieved": s_ach,
+            "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": s_ach / FP64_MATRIX_PEAK_TFLOPS,
+        }
     if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         nf_s, nt_s = (2, 10) if args.config == "c2" else (min(nf, 2), min(nt, 10))
         if big:      # a 2000-baseline, one-channel slice (the full slice would need 16 GB)
             inp = dict(inp, antpairs=antpairs_all[:2000])
             nf_s, nt_s = 1, 1
         out["cpu_baseline"] = cpu_baseline(inp, nf_s, nt_s, m_all)
+        out["cpu_baseline"]["blas_threads"] = out["cpu_baseline"]["cores"]
+        out["cpu_baseline"]["host_cpus"] = len(os.sched_getaffinity(0))
+        # the same path with one BLAS thread, on a smaller slice (bounded CPU time)
+        out["cpu_baseline_single_thread"] = cpu_baseline(inp, 1, min(nt_s, 5), m_all,
+                                                         single_thread=True)
     else:
         out["cpu_baseline"] = None
     print(json.dumps(out))
