@@ -133,16 +133,57 @@ class Comm:
 
     def reduce_rows_(self, A):
         """Sum the (n, ncols) partial matrices of all ranks block row by block row, each block
-        to the rank that owns it (a reduce-scatter done as ``size`` in-place reduces on views:
-        no second copy of an 80 GB matrix).  Returns this rank's rows as a view of ``A``; the
-        other rows of ``A`` are left in an unspecified state."""
+        to the rank that owns it.  Returns this rank's rows; the rows of ``A`` are left in an
+        unspecified state.
+
+        RCCL: ONE reduce-scatter (``reduce_scatter_tensor``) when the rows divide evenly over the
+        ranks -- every GPU then sends and receives on all of its xGMI links at once, where a
+        loop of ``size`` rooted reduces serialises them (0.13 s against 0.9 s for
+        the 80 GB Gram of config 5 on 8 GPUs).  The result is a new (n/size, ncols) tensor: the
+        collective's output may not alias its input.  Otherwise (gloo, or a ragged last block)
+        one in-place reduce per block on views of ``A``."""
         n = A.shape[0]
-        for k in range(self.Get_size()):
+        size = self.Get_size()
+        if self.backend == "nccl" and A.is_cuda and A.is_contiguous() and n % size == 0:
+            out = torch.empty((n // size,) + tuple(A.shape[1:]), dtype=A.dtype, device=A.device)
+            dist.reduce_scatter_tensor(out, A, op=dist.ReduceOp.SUM, group=self.group)
+            return out
+        for k in range(size):
             r0, r1 = self.row_range(n, k)
             if r1 > r0:
                 self.reduce_(A[r0:r1], root=k)
         r0, r1 = self.row_range(n)
         return A[r0:r1]
+
+    def _sym_packed(self, A):
+        from . import _dev
+        n = A.shape[0]
+        assert A.is_cuda and A.is_contiguous() and tuple(A.shape) == (n, n)
+        packed = torch.empty(n * (n + 1) // 2, dtype=torch.float64, device=A.device)
+        _dev.call("hydra_pack_lower", _dev.ptr(A), n, _dev.ptr(packed), _dev.stream_ptr())
+        return packed
+
+    def _sym_unpack(self, packed, A):
+        from . import _dev
+        _dev.call("hydra_unpack_lower", _dev.ptr(packed), A.shape[0], _dev.ptr(A), _dev.stream_ptr())
+        A.hydra_symmetric = True
+        return A
+
+    def reduce_sym_(self, A, root=0):
+        """Sum-reduce an exactly symmetric GPU matrix to ``root`` with only its lower triangle on
+        the wire (half the bytes of ``reduce_``); the root's ``A`` comes back mirrored, hence
+        symmetric bit for bit whatever order the collective summed in."""
+        packed = self._sym_packed(A)
+        self.reduce_(packed, root=root)
+        if self.Get_rank() == root:
+            self._sym_unpack(packed, A)
+        return A
+
+    def allreduce_sym_(self, A):
+        """All-reduce of an exactly symmetric GPU matrix through its packed lower triangle."""
+        packed = self._sym_packed(A)
+        self.allreduce_(packed)
+        return self._sym_unpack(packed, A)
 
     def allgather_rows(self, part, n):
         """Concatenate the ranks' row-block vectors (lengths as in ``row_range``) into the full

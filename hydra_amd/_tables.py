@@ -16,14 +16,27 @@ INFO_BYTES = 12               # per baseline row: packed LDS rows (4) + sqrt wei
 _BL_CACHE = {}
 
 
+def _fingerprint(antpairs, ants):
+    """Cheap content check of a cached (antpairs, ants) pair: length plus the first, the last
+    and ~30 strided pairs, and all antenna names.  A caller that shuffles, reorders or replaces
+    pairs in place changes it (identity alone would return stale indices silently)."""
+    n = len(antpairs)
+    step = max(1, n // 29)
+    picks = tuple((antpairs[k][0], antpairs[k][1]) for k in range(0, n, step))
+    last = (antpairs[-1][0], antpairs[-1][1]) if n else ()
+    return n, picks, last, tuple(np.atleast_1d(np.asarray(ants)).tolist())
+
+
 def baseline_indices(ants, antpairs):
     """Index of each baseline's antennas in ``ants`` (the lookup of
     ptsrc_sampler.py:53-56 / utils.py:102-105).  Returns int32 arrays (bl_i, bl_j).
-    The result is cached per (antpairs, ants) object pair: the heads call this every Gibbs
-    iteration with the same lists (54 615 pairs for HERA-331)."""
+    The result is cached per (antpairs, ants) object pair and re-validated by a content
+    fingerprint on every hit: the heads call this every Gibbs iteration with the same lists
+    (54 615 pairs for HERA-331)."""
     key = (id(antpairs), id(ants))
     hit = _BL_CACHE.get(key)
-    if hit is not None and hit[0] is antpairs and hit[1] is ants and hit[2] == len(antpairs):
+    if hit is not None and hit[0] is antpairs and hit[1] is ants \
+            and hit[2] == _fingerprint(antpairs, ants):
         return hit[3], hit[4]
     ants_l = [a for a in np.atleast_1d(np.asarray(ants)).tolist()]
     pos = {}
@@ -36,7 +49,7 @@ def baseline_indices(ants, antpairs):
         raise IndexError(f"antenna {exc.args[0]} of `antpairs` is not in `ants`") from exc
     if len(_BL_CACHE) > 16:
         _BL_CACHE.clear()
-    _BL_CACHE[key] = (antpairs, ants, len(antpairs), bl_i, bl_j)
+    _BL_CACHE[key] = (antpairs, ants, _fingerprint(antpairs, ants), bl_i, bl_j)
     return bl_i, bl_j
 
 

@@ -196,15 +196,16 @@ gain_pairs_tiled_kernel(const f64x2* __restrict__ g, const double* __restrict__ 
 // v[b,ft] = (x_i + conj(x_j)) * mv[b,ft]
 __global__ void __launch_bounds__(256)
 gain_proj_kernel(const f64x2* __restrict__ x, const int32_t* __restrict__ bl_i,
-                 const int32_t* __restrict__ bl_j, const f64x2* __restrict__ mv, int nft,
+                 const int32_t* __restrict__ bl_j, const f64x2* __restrict__ mv, int nbl, int nft,
                  f64x2* __restrict__ out) {
-  int b = blockIdx.y;
-  int i = bl_i[b], j = bl_j[b];
-  for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nft; k += gridDim.x * blockDim.x) {
-    f64x2 xi = x[(size_t)i * nft + k], xj = x[(size_t)j * nft + k];
-    f64x2 c = {1.0 * (xi.x + xj.x), 1.0 * (xi.y - xj.y)};
-    size_t o = (size_t)b * nft + k;
-    out[o] = cmul(c, mv[o]);
+  for (int b = blockIdx.y; b < nbl; b += gridDim.y) {   // grid.y is capped at 65535
+    int i = bl_i[b], j = bl_j[b];
+    for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nft; k += gridDim.x * blockDim.x) {
+      f64x2 xi = x[(size_t)i * nft + k], xj = x[(size_t)j * nft + k];
+      f64x2 c = {1.0 * (xi.x + xj.x), 1.0 * (xi.y - xj.y)};
+      size_t o = (size_t)b * nft + k;
+      out[o] = cmul(c, mv[o]);
+    }
   }
 }
 
@@ -359,12 +360,12 @@ int hydra_gain_pairs(const double* g, int nvec, int nant, int nft, const double*
 
 int hydra_gain_proj(const double* x, const int32_t* bl_i, const int32_t* bl_j, int nbl,
                     const double* model_vis, int nft, double* out, void* stream) {
-  HYDRA_CHECK_ARG(x && bl_i && bl_j && model_vis && out && nbl > 0 && nft > 0 && nbl <= 65535,
+  HYDRA_CHECK_ARG(x && bl_i && bl_j && model_vis && out && nbl > 0 && nft > 0,
                   "hydra_gain_proj: bad arguments");
-  dim3 grid(std::min((nft + 255) / 256, 1024), nbl);
+  dim3 grid(std::min((nft + 255) / 256, 1024), std::min(nbl, 65535));
   gain_proj_kernel<<<grid, 256, 0, as_stream(stream)>>>(
       reinterpret_cast<const f64x2*>(x), bl_i, bl_j, reinterpret_cast<const f64x2*>(model_vis),
-      nft, reinterpret_cast<f64x2*>(out));
+      nbl, nft, reinterpret_cast<f64x2*>(out));
   HYDRA_CHECK_LAUNCH("hydra_gain_proj");
   return HYDRA_OK;
 }

@@ -271,7 +271,9 @@ prior_epilogue_kernel(double* __restrict__ G, int ns, const double* __restrict__
     int i = (int)(e / ns), j = (int)(e % ns);
     double v = G[e];
     if (prior_std) {
-      v = prior_std[i] * v * prior_std[j];
+      // the same operation order on (i,j) and (j,i), and the one gram_finish_kernel uses on the
+      // lower triangle: a symmetric G stays symmetric bit for bit
+      v = prior_std[i > j ? i : j] * v * prior_std[i > j ? j : i];
       if (i == j) v = 1.0 + v;
     } else if (add_diag && i == j) {
       v += add_diag[i];

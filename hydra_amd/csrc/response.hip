@@ -285,39 +285,42 @@ response_kernel(const f64x2* __restrict__ V, int nf, int nt, int nant, int ns,
 }
 
 __global__ void __launch_bounds__(256)
-subarr_kernel(const f64x2* __restrict__ V, int nant, int ns, int sub, f64x2* __restrict__ out) {
+subarr_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int sub,
+              f64x2* __restrict__ out) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
-  size_t ft = blockIdx.y;
   if (s >= ns) return;
-  const f64x2* vin = V + ft * nant * (size_t)ns + s;
-  f64x2 vs = vin[(size_t)sub * ns];
-  f64x2* o = out + ft * nant * (size_t)ns + s;
-  for (int a = 0; a < nant; ++a) o[(size_t)a * ns] = cmul_conj(vin[(size_t)a * ns], vs);
+  for (size_t ft = blockIdx.y; ft < (size_t)nft; ft += gridDim.y) {   // grid.y is capped at 65535
+    const f64x2* vin = V + ft * nant * (size_t)ns + s;
+    f64x2 vs = vin[(size_t)sub * ns];
+    f64x2* o = out + ft * nant * (size_t)ns + s;
+    for (int a = 0; a < nant; ++a) o[(size_t)a * ns] = cmul_conj(vin[(size_t)a * ns], vs);
+  }
 }
 
 // vis[f,t,i,j] = sum_s conj(V_i) V_j for j >= i: one wave per (i,j) pair, lanes stride over
 // sources, wave-level shuffle reduction (fixed order -> bitwise reproducible).
 __global__ void __launch_bounds__(256)
-vis_sum_kernel(const f64x2* __restrict__ V, int nant, int ns, f64x2* __restrict__ vis) {
+vis_sum_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, f64x2* __restrict__ vis) {
   int lane = threadIdx.x & 63;
   int wave = threadIdx.x >> 6;
-  size_t ft = blockIdx.y;
   int p = blockIdx.x * 4 + wave;
   if (p >= nant * nant) return;
   int i = p / nant, j = p - i * nant;
-  f64x2 acc = {0.0, 0.0};
-  if (j >= i) {
-    const f64x2* vi = V + (ft * nant + i) * (size_t)ns;
-    const f64x2* vj = V + (ft * nant + j) * (size_t)ns;
-    for (int s = lane; s < ns; s += 64) {
-      f64x2 r = cmul_conj(vi[s], vj[s]);
-      acc.x += r.x;
-      acc.y += r.y;
+  for (size_t ft = blockIdx.y; ft < (size_t)nft; ft += gridDim.y) {   // grid.y is capped at 65535
+    f64x2 acc = {0.0, 0.0};
+    if (j >= i) {
+      const f64x2* vi = V + (ft * nant + i) * (size_t)ns;
+      const f64x2* vj = V + (ft * nant + j) * (size_t)ns;
+      for (int s = lane; s < ns; s += 64) {
+        f64x2 r = cmul_conj(vi[s], vj[s]);
+        acc.x += r.x;
+        acc.y += r.y;
+      }
+      acc.x = wave_sum(acc.x);
+      acc.y = wave_sum(acc.y);
     }
-    acc.x = wave_sum(acc.x);
-    acc.y = wave_sum(acc.y);
+    if (lane == 0) vis[ft * nant * nant + p] = acc;
   }
-  if (lane == 0) vis[ft * nant * nant + p] = acc;
 }
 
 // ---------------------------------------------------------------- gains / row factors
@@ -325,8 +328,8 @@ vis_sum_kernel(const f64x2* __restrict__ V, int nant, int ns, f64x2* __restrict_
 __global__ void __launch_bounds__(256)
 apply_gains_kernel(f64x2* __restrict__ v, const f64x2* __restrict__ gains,
                    const f64x2* __restrict__ pert, const int32_t* __restrict__ bl_i,
-                   const int32_t* __restrict__ bl_j, int nft) {
-  int b = blockIdx.y;
+                   const int32_t* __restrict__ bl_j, int nbl, int nft) {
+  for (int b = blockIdx.y; b < nbl; b += gridDim.y) {   // grid.y is capped at 65535
   int i = bl_i[b], j = bl_j[b];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nft; k += gridDim.x * blockDim.x) {
     f64x2 gi = gains[(size_t)i * nft + k];
@@ -342,13 +345,14 @@ apply_gains_kernel(f64x2* __restrict__ v, const f64x2* __restrict__ gains,
     size_t o = (size_t)b * nft + k;
     v[o] = cmul(v[o], fac);
   }
+  }
 }
 
 __global__ void __launch_bounds__(256)
 row_factors_kernel(const f64x2* __restrict__ gains, const double* __restrict__ w,
-                   const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nft,
-                   f64x2* __restrict__ gg, f64x2* __restrict__ rows) {
-  int b = blockIdx.y;
+                   const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
+                   int nft, f64x2* __restrict__ gg, f64x2* __restrict__ rows) {
+  for (int b = blockIdx.y; b < nbl; b += gridDim.y) {   // grid.y is capped at 65535
   int i = bl_i[b], j = bl_j[b];
   for (int k = blockIdx.x * blockDim.x + threadIdx.x; k < nft; k += gridDim.x * blockDim.x) {
     f64x2 fac = {1.0, 0.0};
@@ -365,6 +369,7 @@ row_factors_kernel(const f64x2* __restrict__ gains, const double* __restrict__ w
       f64x2 r = {fac.x * rt, fac.y * rt};
       rows[o] = r;
     }
+  }
   }
 }
 
@@ -477,20 +482,20 @@ int hydra_vis_subarr(const double* V, int nf, int nt, int nant, int ns, int suba
                   "hydra_vis_subarr: bad arguments");
   HYDRA_CHECK_ARG(subarr_ant >= 0 && subarr_ant < nant, "hydra_vis_subarr: subarr_ant=%d out of range",
                   subarr_ant);
-  HYDRA_CHECK_ARG((long long)nf * nt <= 65535, "hydra_vis_subarr: nf*nt must be <= 65535");
-  dim3 grid((ns + 255) / 256, nf * nt);
-  subarr_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(V), nant, ns,
-                                                     subarr_ant, reinterpret_cast<f64x2*>(out));
+  HYDRA_CHECK_ARG((long long)nf * nt <= 2147483647LL, "hydra_vis_subarr: nf*nt too large");
+  dim3 grid((ns + 255) / 256, std::min(nf * nt, 65535));
+  subarr_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(V), nf * nt, nant,
+                                                     ns, subarr_ant, reinterpret_cast<f64x2*>(out));
   HYDRA_CHECK_LAUNCH("hydra_vis_subarr");
   return HYDRA_OK;
 }
 
 int hydra_vis_sum(const double* V, int nf, int nt, int nant, int ns, double* vis, void* stream) {
   HYDRA_CHECK_ARG(V && vis && nf > 0 && nt > 0 && nant > 0 && ns > 0, "hydra_vis_sum: bad arguments");
-  HYDRA_CHECK_ARG((long long)nf * nt <= 65535, "hydra_vis_sum: nf*nt must be <= 65535");
-  dim3 grid((nant * nant + 3) / 4, nf * nt);
-  vis_sum_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(V), nant, ns,
-                                                      reinterpret_cast<f64x2*>(vis));
+  HYDRA_CHECK_ARG((long long)nf * nt <= 2147483647LL, "hydra_vis_sum: nf*nt too large");
+  dim3 grid((nant * nant + 3) / 4, std::min(nf * nt, 65535));
+  vis_sum_kernel<<<grid, 256, 0, as_stream(stream)>>>(reinterpret_cast<const f64x2*>(V), nf * nt, nant,
+                                                      ns, reinterpret_cast<f64x2*>(vis));
   HYDRA_CHECK_LAUNCH("hydra_vis_sum");
   return HYDRA_OK;
 }
@@ -499,12 +504,11 @@ int hydra_apply_gains(double* v, const double* gains, const double* pert, const 
                       const int32_t* bl_j, int nbl, int nf, int nt, void* stream) {
   HYDRA_CHECK_ARG(v && gains && bl_i && bl_j && nbl > 0 && nf > 0 && nt > 0,
                   "hydra_apply_gains: bad arguments");
-  HYDRA_CHECK_ARG(nbl <= 65535, "hydra_apply_gains: nbl must be <= 65535");
   int nft = nf * nt;
-  dim3 grid(std::min((nft + 255) / 256, 1024), nbl);
+  dim3 grid(std::min((nft + 255) / 256, 1024), std::min(nbl, 65535));
   apply_gains_kernel<<<grid, 256, 0, as_stream(stream)>>>(
       reinterpret_cast<f64x2*>(v), reinterpret_cast<const f64x2*>(gains),
-      reinterpret_cast<const f64x2*>(pert), bl_i, bl_j, nft);
+      reinterpret_cast<const f64x2*>(pert), bl_i, bl_j, nbl, nft);
   HYDRA_CHECK_LAUNCH("hydra_apply_gains");
   return HYDRA_OK;
 }
@@ -514,11 +518,10 @@ int hydra_row_factors(const double* gains, const double* inv_noise, const int32_
                       void* stream) {
   HYDRA_CHECK_ARG(bl_i && bl_j && nbl > 0 && nf > 0 && nt > 0 && (gg || rows),
                   "hydra_row_factors: bad arguments");
-  HYDRA_CHECK_ARG(nbl <= 65535, "hydra_row_factors: nbl must be <= 65535");
   int nft = nf * nt;
-  dim3 grid(std::min((nft + 255) / 256, 1024), nbl);
+  dim3 grid(std::min((nft + 255) / 256, 1024), std::min(nbl, 65535));
   row_factors_kernel<<<grid, 256, 0, as_stream(stream)>>>(
-      reinterpret_cast<const f64x2*>(gains), inv_noise, bl_i, bl_j, nft,
+      reinterpret_cast<const f64x2*>(gains), inv_noise, bl_i, bl_j, nbl, nft,
       reinterpret_cast<f64x2*>(gg), reinterpret_cast<f64x2*>(rows));
   HYDRA_CHECK_LAUNCH("hydra_row_factors");
   return HYDRA_OK;

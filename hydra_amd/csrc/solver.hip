@@ -206,6 +206,47 @@ symv_reduce_kernel(const double* __restrict__ part, int n, int nbk, double* __re
   }
 }
 
+// ---------------------------------------------------------------- packed lower triangle
+// The Gram of a rank's rows is exactly symmetric, so the sum over GPUs (comm.Reduce of the full
+// square at ptsrc_sampler.py:86) only needs the lower triangle on the wire: 4 n (n+1) bytes
+// instead of 8 n^2.  packed[i (i+1) / 2 + j] = A[i][j], j <= i.  Unpacking mirrors through LDS
+// (64 x 64 tiles) so that both triangles are written along rows; the result is symmetric bit for
+// bit whatever order the collective summed in.
+__global__ void __launch_bounds__(256)
+pack_lower_kernel(const double* __restrict__ A, int n, double* __restrict__ packed) {
+  for (int i = blockIdx.x; i < n; i += gridDim.x) {
+    const double* row = A + (size_t)i * n;
+    double* dst = packed + (size_t)i * (i + 1) / 2;
+    for (int j = threadIdx.x; j <= i; j += 256) dst[j] = row[j];
+  }
+}
+
+__global__ void __launch_bounds__(256)
+unpack_lower_kernel(const double* __restrict__ packed, int n, double* __restrict__ A) {
+  __shared__ double tile[64][65];
+  const long long t = blockIdx.x;
+  int bi = (int)((sqrt(8.0 * (double)t + 1.0) - 1.0) * 0.5);
+  while ((long long)(bi + 1) * (bi + 2) / 2 <= t) ++bi;
+  while ((long long)bi * (bi + 1) / 2 > t) --bi;
+  const int bj = (int)(t - (long long)bi * (bi + 1) / 2);
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;
+    const int gi = bi * 64 + r, gj = bj * 64 + c;
+    double v = 0.0;
+    if (gi < n && gj <= gi) {
+      v = packed[(size_t)gi * (gi + 1) / 2 + gj];
+      A[(size_t)gi * n + gj] = v;
+    }
+    tile[r][c] = v;
+  }
+  __syncthreads();
+  for (int e = threadIdx.x; e < 4096; e += 256) {
+    const int r = e >> 6, c = e & 63;             // entry (r, c) of the transposed tile
+    const int gi = bj * 64 + r, gj = bi * 64 + c;
+    if (gi < n && gj < n && gj > gi) A[(size_t)gi * n + gj] = tile[c][r];
+  }
+}
+
 // ---------------------------------------------------------------- symv without a workspace
 // hydra_symv_static: the pieces of symv_blocks_kernel go to a file-scope device array instead of
 // a caller workspace, for callers that cannot allocate (HIP graph capture, serving loops).
@@ -490,6 +531,22 @@ int hydra_symv_batched(const double* A, int n, int nb, const double* x, double* 
   return HYDRA_OK;
 }
 
+int hydra_pack_lower(const double* A, int n, double* packed, void* stream) {
+  HYDRA_CHECK_ARG(A && packed && n > 0, "hydra_pack_lower: bad arguments (n=%d)", n);
+  pack_lower_kernel<<<std::min(n, 65535), 256, 0, as_stream(stream)>>>(A, n, packed);
+  HYDRA_CHECK_LAUNCH("hydra_pack_lower");
+  return HYDRA_OK;
+}
+
+int hydra_unpack_lower(const double* packed, int n, double* A, void* stream) {
+  HYDRA_CHECK_ARG(A && packed && n > 0, "hydra_unpack_lower: bad arguments (n=%d)", n);
+  long long nb = (n + 63) / 64, ntile = nb * (nb + 1) / 2;
+  HYDRA_CHECK_ARG(ntile <= 2147483647LL, "hydra_unpack_lower: n=%d is too large", n);
+  unpack_lower_kernel<<<(unsigned)ntile, 256, 0, as_stream(stream)>>>(packed, n, A);
+  HYDRA_CHECK_LAUNCH("hydra_unpack_lower");
+  return HYDRA_OK;
+}
+
 int hydra_symv_static_max_n(void) { return SYMV_STATIC_MAX_N; }
 
 int hydra_symv_static(const double* A, int n, const double* x, double* y, int accumulate,
@@ -544,7 +601,9 @@ int hydra_cg_state_len(void) { return CG_STATE_LEN; }
 
 size_t hydra_cg_workspace_bytes(int n) {
   if (n <= 0) return 0;
-  return ((size_t)3 * n + CG_STATE_LEN) * sizeof(double) + hydra_symv_workspace_bytes(n, 1);
+  // the half-read symmetric product is only taken from n = 4096 on (below, one launch beats two)
+  return ((size_t)3 * n + CG_STATE_LEN) * sizeof(double) +
+         (n >= 4096 ? hydra_symv_workspace_bytes(n, 1) : 0);
 }
 
 int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int maxiters,
@@ -561,7 +620,7 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
   double* ap = p + n;
   double* st = ap + n;
   void* sv_ws = st + CG_STATE_LEN;
-  size_t sv_bytes = hydra_symv_workspace_bytes(n, 1);
+  size_t sv_bytes = n >= 4096 ? hydra_symv_workspace_bytes(n, 1) : 0;
   hipStream_t s = as_stream(stream);
   // A p: half the matrix is read when the caller vouches for exact symmetry
   auto matvec = [&](const double* v, double* out) {

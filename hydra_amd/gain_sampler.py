@@ -22,7 +22,18 @@ import torch
 
 from . import _dev
 
-_INDEX_CACHE = {}
+_INDEX_CACHE = {}          # (id(A_real), id(A_imag)) -> (A_real, A_imag, _Index); bounded, see below
+_INDEX_CACHE_MAX = 8
+
+
+def _remember(A_real, A_imag, idx):
+    """Keep the index form of a projector pair; the cache holds the matrices alive (so that an id
+    is never reused while its entry exists) and drops the oldest entry beyond a few pairs --
+    every ``proj_operator`` call used to pin its matrices, device tables and an Nant^2 pair table
+    for the life of the process."""
+    while len(_INDEX_CACHE) >= _INDEX_CACHE_MAX:
+        _INDEX_CACHE.pop(next(iter(_INDEX_CACHE)))
+    _INDEX_CACHE[(id(A_real), id(A_imag))] = (A_real, A_imag, idx)
 
 
 def proj_operator(ants, antpairs):
@@ -41,7 +52,7 @@ def proj_operator(ants, antpairs):
         A_imag[i, ant_idx[ant2]] += -1
     i1 = np.array([ant_idx[p[0]] for p in antpairs], dtype=np.int32)
     i2 = np.array([ant_idx[p[1]] for p in antpairs], dtype=np.int32)
-    _INDEX_CACHE[(id(A_real), id(A_imag))] = (A_real, A_imag, _Index(i1, i2, nants))
+    _remember(A_real, A_imag, _Index(i1, i2, nants))
     return A_real, A_imag
 
 
@@ -104,7 +115,7 @@ def _index_of(A_real, A_imag):
             assert cols.size == 1 and Ar[k, cols[0]] == 2, "not a baseline projector"
             i1[k] = i2[k] = cols[0]
     idx = _Index(i1, i2, nants)
-    _INDEX_CACHE[(id(A_real), id(A_imag))] = (A_real, A_imag, idx)
+    _remember(A_real, A_imag, idx)
     return idx
 
 

@@ -22,6 +22,28 @@ from . import _dev
 CHECK_EVERY = 16
 
 
+def mark_symmetric(A):
+    """Tag a matrix as exactly symmetric (A == A.T bit for bit), as the Gram finish kernels leave
+    it: ``cg`` then reads half of it per product without checking.  Returns ``A``."""
+    if isinstance(A, torch.Tensor):
+        A.hydra_symmetric = True
+    return A
+
+
+def _is_symmetric(A):
+    """Exact symmetry of a square GPU matrix.  Matrices built by this package carry a tag
+    (``mark_symmetric``); anything else is compared with its transpose in row blocks, so that no
+    n^2 temporary is made (the 100 000-source operator is 80 GB)."""
+    if getattr(A, "hydra_symmetric", False):
+        return True
+    n = A.shape[0]
+    step = max(1, min(n, (1 << 26) // max(n, 1)))          # <= 64 Mi entries per comparison
+    for i in range(0, n, step):
+        if not torch.equal(A[i:i + step], A[:, i:i + step].T):
+            return False
+    return True
+
+
 def _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0):
     A = _dev.f64(Amat)
     b = _dev.f64(bvec)
@@ -31,9 +53,9 @@ def _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0):
     ws = _dev.workspace(_dev._lib.query("hydra_cg_workspace_bytes", n))
     import ctypes
     iters = ctypes.c_int(0)
-    # the GCR operators are symmetric by construction; checked (one pass over A) so that an
-    # unsymmetric Amat still gets the reference's A @ p
-    symmetric = bool(torch.equal(A, A.T))
+    # the GCR operators are symmetric by construction and tagged so by the functions that build
+    # them; an untagged matrix is checked, so that an unsymmetric Amat still gets A @ p
+    symmetric = n >= 4096 and (getattr(Amat, "hydra_symmetric", False) or _is_symmetric(A))
     _dev.call("hydra_cg_solve_dense", _dev.ptr(A), _dev.ptr(b), _dev.ptr(x), n, int(maxiters),
               float(abs_tol), int(bool(use_norm_tol)), int(symmetric), CHECK_EVERY,
               ctypes.byref(iters),
@@ -72,22 +94,70 @@ def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
     return x, int(st[2].item())
 
 
+def _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, comm):
+    """The reference's ``cg(..., linear_op=, comm=)`` (linear_solver.py:441-499): ``linear_op``
+    is COLLECTIVE (every rank must call it the same number of times; it synchronises its own
+    input) and only the root's return value is valid -- e.g. ``apply_lhs_no_rot_mpi``, which
+    returns zeros elsewhere (sh_sampler.py:405-494).  The root drives: after every step its
+    direction vector and CG state (r.r, done flag, iteration count) are broadcast -- ONE
+    broadcast of p and the state together, where the reference sends the finished flag and
+    ``pvec`` separately (:466-476, :495-496) -- so every rank sees the root's flag and stops
+    after the same number of operator calls.  Non-root ranks run the same fused step on their
+    (meaningless) operator result; their x is replaced by the root's at the end."""
+    as_torch = _dev.is_torch(bvec)
+    b = _dev.f64(bvec)
+    n = b.numel()
+    x = _dev.f64(x0).clone() if x0 is not None else torch.zeros_like(b)
+    r = torch.empty_like(b)
+    nst = _dev._lib.query("hydra_cg_state_len")
+    ps = torch.zeros(n + nst, dtype=torch.float64, device=b.device)   # p and the state: one message
+    p, st = ps[:n], ps[n:]
+    sp = _dev.stream_ptr()
+
+    def op(v):
+        out = linear_op(v if as_torch else v.cpu().numpy())
+        return _dev.f64(out)
+
+    _dev.call("hydra_cg_init", n, _dev.ptr(b), _dev.ptr(op(x)), _dev.ptr(r), _dev.ptr(p),
+              _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
+    comm.bcast_(ps, root=0)
+    it = 0
+    every = CHECK_EVERY if as_torch else 1
+    while True:
+        if float(st[1].item()) != 0.0 or it >= maxiters:      # the root's flag, on every rank
+            break
+        for _ in range(min(every, maxiters - it)):
+            ap = op(p)
+            _dev.call("hydra_cg_step", n, _dev.ptr(ap), _dev.ptr(x), _dev.ptr(r), _dev.ptr(p),
+                      _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
+            comm.bcast_(ps, root=0)
+            it += 1
+    return x, int(st[2].item())
+
+
 def cg(Amat, bvec, maxiters=1000, abs_tol=1e-8, use_norm_tol=False, x0=None, linear_op=None,
        comm=None, return_iters=False):
     """Conjugate-gradient solve of ``Amat x = bvec`` (linear_solver.py:378-509).
 
-    ``linear_op`` (callable) replaces ``Amat`` when given.  With ``comm`` every rank runs the
-    same iteration on the (already synchronised) operator results and the root's solution is
-    broadcast at the end, so all ranks return the same ``x`` as in the reference (:506-508).
+    ``linear_op`` (callable) replaces ``Amat`` when given.  With ``comm`` the solve is driven by
+    the root as in the reference: only the root's operator results (or matrix) count, and its
+    solution is broadcast at the end, so all ranks return the same ``x`` (:441-508).  An
+    operator that already returns the summed result on EVERY rank (an all-reduce inside, e.g.
+    ``RowShardedOperator`` or ``sh_sampler.LhsOperator``) needs no ``comm`` here: every rank then
+    runs the same iteration on identical data, one collective per iteration instead of three.
     """
     if x0 is not None:
         assert tuple(x0.shape) == tuple(bvec.shape), (
             "Initial guess x0 has a different shape to bvec")
         assert x0.dtype == bvec.dtype, "Initial guess x0 has a different type to bvec"
-    if linear_op is None:
-        x, iters = _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0)
-    else:
+    if linear_op is not None and comm is not None:
+        x, iters = _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, comm)
+    elif linear_op is not None:
         x, iters = _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op)
+    elif comm is None or comm.Get_rank() == 0:
+        x, iters = _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0)
+    else:       # only the root's matrix counts (:441-443); its solution arrives below
+        x, iters = torch.zeros_like(_dev.f64(bvec)), 0
     if comm is not None:
         comm.barrier()
         comm.bcast_(x, root=0)

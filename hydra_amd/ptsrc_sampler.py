@@ -293,7 +293,7 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         b += oa
     elif comm is not None:
         # sum over ranks (comm.Reduce at ptsrc_sampler.py:86,132), then prior + omega_a on root
-        comm.reduce_(A, root=0)
+        comm.reduce_sym_(A, root=0)      # lower triangle on the wire, mirrored on arrival
         comm.reduce_(b, root=0)
         if myid == 0:
             _dev.call("hydra_prior_epilogue", _dev.ptr(A), ns, _dev.ptr(sigma), _dev.ptr(None), st)
@@ -301,6 +301,8 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         else:
             A = torch.zeros((1, 1), dtype=torch.float64, device=A.device)
             b = torch.zeros((1,), dtype=torch.float64, device=b.device)
+    if _dev.is_torch(ref) and not shard_rows and A.shape[0] == A.shape[1]:
+        A.hydra_symmetric = True      # mirrored exactly by the Gram finish / unpack kernels
     return _dev.like(ref, A), _dev.like(ref, b)
 
 

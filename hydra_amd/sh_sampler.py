@@ -154,10 +154,12 @@ def construct_rhs_no_rot(data, inv_noise_var, inv_prior_var, omega_0, omega_1, a
 
 
 def construct_rhs_no_rot_mpi(comm, data, inv_noise_var, inv_prior_var, omega_a, omega_n, a_0,
-                             vis_response):
+                             vis_response, all_ranks=False):
     """Right-hand side from data split over ranks (sh_sampler.py:405-448): ``omega_a`` is
     taken from the root (non-root buffers are overwritten, as in the reference), the data
-    terms are summed over ranks, and only the root returns the full vector."""
+    terms are summed over ranks, and only the root returns the full vector.
+    ``all_ranks=True`` (an addition): the sum is an all-reduce and every rank returns the full
+    vector -- what a CG with ``LhsOperator`` needs."""
     myid = comm.Get_rank() if comm is not None else 0
     if comm is not None:
         if myid != 0:
@@ -165,7 +167,10 @@ def construct_rhs_no_rot_mpi(comm, data, inv_noise_var, inv_prior_var, omega_a, 
         comm.Bcast(omega_a, root=0)
     R = _dev.c128(vis_response)
     term = _data_term(data, inv_noise_var, omega_n, R)
-    if comm is not None:
+    if comm is not None and all_ranks:
+        comm.allreduce_(term)
+        myid = 0
+    elif comm is not None:
         comm.reduce_(term, root=0)
         comm.barrier()
     if myid == 0:
@@ -215,6 +220,30 @@ def apply_lhs_no_rot_mpi(comm, a_cr, inv_noise_var, inv_prior_var, vis_response)
     return _dev.like(a_cr, torch.zeros_like(a))
 
 
+class LhsOperator:
+    """(R^T N^-1 R + S^-1) a with the rows of R split over the ranks of ``comm``, for
+    ``linear_solver.cg(None, b, linear_op=op)`` WITHOUT ``comm``: each application is two passes
+    over the rank's rows and ONE all-reduce of the (Nm,) result, after which every rank holds
+    the same vector and runs the same fused CG step on it.  That one collective replaces, per
+    iteration, the Bcast + Reduce of ``apply_lhs_no_rot_mpi`` (sh_sampler.py:465,485) and the
+    finished-flag and ``pvec`` broadcasts of the root-driven ``cg`` (linear_solver.py:473,496);
+    the CG scalars need no message at all (every rank computes them from identical data)."""
+
+    def __init__(self, comm, inv_noise_var, inv_prior_var, vis_response):
+        self.comm = comm
+        self.R = _dev.c128(vis_response)
+        self.w = _dev.f64(inv_noise_var).reshape(-1)
+        self.ip = _dev.f64(inv_prior_var)
+        assert self.w.numel() == self.R.shape[0] and self.ip.numel() == self.R.shape[1]
+
+    def __call__(self, a_cr):
+        a = _dev.f64(a_cr)
+        tot = _noise_term(a, self.w, self.R)
+        if self.comm is not None:
+            self.comm.allreduce_(tot)
+        return _dev.like(a_cr, tot + self.ip * a)
+
+
 def lhs_matrix(inv_noise_var, inv_prior_var, vis_response, comm=None):
     """The SH left-hand-side operator as an explicit matrix
     A = Re(R^H N^-1 R) + diag(S^-1), built once on the FP64 matrix cores (csrc/gram.hip), so
@@ -231,7 +260,9 @@ def lhs_matrix(inv_noise_var, inv_prior_var, vis_response, comm=None):
               _dev.ptr(ip if comm is None else None), _dev.ptr(A), _dev.ptr(ws), ws.numel(),
               _dev.stream_ptr())
     if comm is not None:
-        comm.allreduce_(A)
+        comm.allreduce_sym_(A)
         _dev.call("hydra_prior_epilogue", _dev.ptr(A), nm, _dev.ptr(None), _dev.ptr(ip),
                   _dev.stream_ptr())
+    if _dev.is_torch(vis_response):
+        A.hydra_symmetric = True      # mirrored exactly by the Gram finish kernel
     return _dev.like(vis_response, A)

@@ -277,6 +277,13 @@ size_t hydra_symv_workspace_bytes(int n, int nb);
 int hydra_symv_batched(const double* A, int n, int nb, const double* x, double* y, int accumulate,
                        void* workspace, size_t workspace_bytes, void* stream);
 
+/* Lower triangle of a symmetric matrix in packed row order, packed[i (i+1) / 2 + j] = A[i][j] for
+ * j <= i, and back (both triangles written, exactly symmetric).  The sum of the ranks' Grams
+ * (comm.Reduce of the full (Ns,Ns) square, ptsrc_sampler.py:86; sh_sampler.py:485 for the SH
+ * left-hand side) then moves 4 n (n+1) instead of 8 n^2 bytes over xGMI.  packed: n (n+1) / 2 f64. */
+int hydra_pack_lower(const double* A, int n, double* packed, void* stream);
+int hydra_unpack_lower(const double* packed, int n, double* A, void* stream);
+
 /* hydra_symv_batched for one matrix WITHOUT a workspace argument and without any allocation: the
  * per-block-column pieces go to a device array inside the library (8 MiB on every GPU the library
  * runs on, held until the process ends).  No counterpart in the reference: it is for callers that

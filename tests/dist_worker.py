@@ -285,6 +285,160 @@ def case_cosmo(comm):
     comm.barrier()
 
 
+def case_shmpi(comm):
+    """SH head with the visibility rows split over ranks: construct_rhs_no_rot_mpi,
+    apply_lhs_no_rot_mpi, lhs_matrix(comm=) and the reference's own solve pattern
+    cg(None, b, linear_op=apply_lhs_no_rot_mpi(comm, ...), x0=, comm=comm) (example.py:1014-1052;
+    sh_sampler.py:405-494; linear_solver.py:441-508) == the single-process system and solution;
+    plus the one-collective-per-iteration form (LhsOperator, every rank iterates)."""
+    import hydra_amd as hy
+    from hydra_amd import sh_sampler
+    rank, size = comm.Get_rank(), comm.Get_size()
+    rng = np.random.RandomState(21)
+    m, nm = 600, 37
+    R = (rng.randn(m, nm) + 1j * rng.randn(m, nm)) * 0.05
+    w = 300.0 + 100.0 * rng.rand(m)
+    ip = 50.0 + 50.0 * rng.rand(nm)
+    d = rng.randn(m) + 1j * rng.randn(m)
+    om_n = (rng.randn(m) + 1j * rng.randn(m)) / np.sqrt(2)
+    om_a = rng.randn(nm)
+    a0 = 0.1 * rng.randn(nm)
+    x0 = 0.01 * rng.randn(nm)
+    b1 = sh_sampler.construct_rhs_no_rot(d, w, ip, om_a, om_n, a0, R)
+    A1 = sh_sampler.lhs_matrix(w, ip, R)
+    x_ref = np.linalg.solve(A1, b1)
+    rows = np.array_split(np.arange(m), size)[rank]
+    Rk, wk, dk, onk = R[rows], w[rows], d[rows], om_n[rows]
+    # right-hand side: root's omega_a counts, non-root buffers are overwritten (:417-420)
+    oa = om_a.copy() if rank == 0 else np.full(nm, 5.0)     # (no rank-dependent draws from rng)
+    b2 = sh_sampler.construct_rhs_no_rot_mpi(comm, dk, wk, ip, oa, onk, a0, Rk)
+    assert np.array_equal(oa, om_a)
+    if rank == 0:
+        assert np.max(np.abs(b2 - b1)) <= 1e-12 * np.max(np.abs(b1))
+    else:
+        assert np.all(b2 == 0.0)
+    # operator: root's vector counts
+    v = rng.randn(nm)
+    vk = v.copy() if rank == 0 else np.full(nm, 7.0)
+    y2 = sh_sampler.apply_lhs_no_rot_mpi(comm, vk, wk, ip, Rk)
+    assert np.array_equal(vk, v)
+    if rank == 0:
+        assert np.max(np.abs(y2 - A1 @ v)) <= 1e-12 * np.max(np.abs(A1 @ v))
+    else:
+        assert np.all(y2 == 0.0)
+    A2 = sh_sampler.lhs_matrix(wk, ip, Rk, comm=comm)
+    assert np.max(np.abs(A2 - A1)) <= 1e-12 * np.max(np.abs(A1)) and np.array_equal(A2, A2.T)
+    # the reference's solve, verbatim: collective operator valid on the root only, comm=comm
+    bk = b2 if rank == 0 else np.zeros(nm)
+    x0k = x0.copy()
+    x, iters = hy.linear_solver.cg(
+        None, bk, maxiters=300, abs_tol=1e-11, x0=x0k, comm=comm, return_iters=True,
+        linear_op=lambda a: sh_sampler.apply_lhs_no_rot_mpi(comm, a, wk, ip, Rk))
+    assert 0 < iters < 300
+    assert np.max(np.abs(x - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))      # on EVERY rank
+    # GPU-tensor operands: the flag is read every CHECK_EVERY iterations, steps past convergence
+    # are no-ops on every rank
+    dev = torch.device("cuda")
+    Rk_d, wk_d, ip_d = (torch.as_tensor(t, device=dev) for t in (Rk, wk, ip))
+    xt = hy.linear_solver.cg(
+        None, torch.as_tensor(bk, device=dev), maxiters=300, abs_tol=1e-11,
+        x0=torch.as_tensor(x0, device=dev), comm=comm,
+        linear_op=lambda a: sh_sampler.apply_lhs_no_rot_mpi(comm, a, wk_d, ip_d, Rk_d))
+    assert np.max(np.abs(xt.cpu().numpy() - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+    # one collective per iteration: every rank iterates on identical data, no comm in cg
+    b3 = sh_sampler.construct_rhs_no_rot_mpi(comm, dk, wk, ip, om_a.copy(), onk, a0, Rk,
+                                             all_ranks=True)
+    assert np.max(np.abs(b3 - b1)) <= 1e-12 * np.max(np.abs(b1))
+    op = sh_sampler.LhsOperator(comm, wk, ip, Rk)
+    x3, it3 = hy.linear_solver.cg(None, b3, maxiters=300, abs_tol=1e-11, x0=x0, linear_op=op,
+                                  return_iters=True)
+    assert it3 == iters
+    assert np.max(np.abs(x3 - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+    # dense matrix + comm: only the root's matrix counts, every rank gets the solution
+    Ak = A2 if rank == 0 else np.zeros((nm, nm))
+    x4 = hy.linear_solver.cg(Ak, bk, maxiters=300, abs_tol=1e-11, comm=comm)
+    assert np.max(np.abs(x4 - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+    comm.barrier()
+
+
+def case_gainmpi(comm):
+    """Gain head with the frequency channels split over ranks: construct_rhs_mpi and
+    apply_operator_mpi (gain_sampler.py:145-301, Bcast + Allreduce per call) and the CG with one
+    all-reduce of the operator result per iteration (the driver's pattern, example.py:700-722)
+    == the single-process right-hand side, operator and solution."""
+    import hydra_amd as hy
+    from hydra_amd import gain_sampler as gs
+    rank, size = comm.Get_rank(), comm.Get_size()
+    rng = np.random.RandomState(31)
+    nant, nf, nt = 6, 4, 5
+    ants = np.arange(nant)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    nbl = len(antpairs)
+    freqs, times = np.linspace(100.0, 120.0, nf), np.linspace(0.2, 0.5, nt)
+    Fb, _, _ = hy.utils.partial_fourier_basis_2d_from_nmax(freqs, times, 1, 1, 20.0, 0.3)
+    nmodes = Fb.shape[0]
+    ps = 0.05 + 0.05 * rng.rand(nmodes)
+    shape = (nbl, nf, nt)
+    mv = rng.randn(*shape) + 1j * rng.randn(*shape)
+    w = 300.0 + 100.0 * rng.rand(*shape)
+    resid = rng.randn(*shape) + 1j * rng.randn(*shape)
+    om_y = (rng.randn(nant, nmodes) + 1j * rng.randn(nant, nmodes)) / np.sqrt(2)
+    om_r = (rng.randn(*shape) + 1j * rng.randn(*shape)) / np.sqrt(2)
+    A_real, A_imag = gs.proj_operator(ants, antpairs)
+    b1 = gs.construct_rhs_mpi(None, resid, w, ps, A_real, A_imag, mv, Fb, omega_y=om_y, omega_r=om_r)
+    n = 2 * nant * nmodes
+    v = rng.randn(n)
+    y1 = gs.apply_operator_mpi(None, v, w, ps, A_real, A_imag, mv, Fb)
+    op1 = gs.GainOperator(w, ps, A_real, A_imag, mv, Fb)
+    x_ref = hy.linear_solver.cg(None, b1, linear_op=op1.apply, use_norm_tol=True, abs_tol=1e-11,
+                                maxiters=500)
+    f = np.array_split(np.arange(nf), size)[rank]
+    mvk, wk, rk, ork, Fk = mv[:, f], w[:, f], resid[:, f], om_r[:, f], np.ascontiguousarray(Fb[:, f])
+    oy = om_y if rank == 0 else np.zeros_like(om_y)
+    b2 = gs.construct_rhs_mpi(comm, rk, wk, ps, A_real, A_imag, mvk, Fk, omega_y=oy, omega_r=ork)
+    assert np.max(np.abs(b2 - b1)) <= 1e-12 * np.max(np.abs(b1))          # Allreduce: every rank
+    vk = v if rank == 0 else np.zeros(n)
+    y2 = gs.apply_operator_mpi(comm, vk, wk, ps, A_real, A_imag, mvk, Fk)
+    if rank == 0:
+        assert np.max(np.abs(y2 - y1)) <= 1e-12 * np.max(np.abs(y1))
+    opk = gs.GainOperator(wk, ps, A_real, A_imag, mvk, Fk)
+
+    def lin(x):
+        t = opk.local(x)
+        comm.allreduce_(t)
+        return x + t
+    dev = torch.device("cuda")
+    x2, iters = hy.linear_solver.cg(None, torch.as_tensor(b2, device=dev), linear_op=lin,
+                                    use_norm_tol=True, abs_tol=1e-11, maxiters=500, return_iters=True)
+    assert 0 < iters < 500
+    assert np.max(np.abs(x2.cpu().numpy() - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+    comm.barrier()
+
+
+def case_symreduce(comm):
+    """Packed-lower-triangle reduce / all-reduce of a symmetric matrix (hydra_pack_lower /
+    hydra_unpack_lower around the collective) == the full-square sum, exactly symmetric."""
+    rank, size = comm.Get_rank(), comm.Get_size()
+    dev = torch.device("cuda")
+    for n in (1, 63, 64, 65, 200):
+        rng = np.random.RandomState(100 + n)
+        mats = [rng.randn(n, n) for _ in range(size)]
+        mats = [a + a.T for a in mats]
+        want = sum(mats)
+        A = torch.as_tensor(mats[rank], device=dev).contiguous()
+        comm.reduce_sym_(A, root=0)
+        if rank == 0:
+            got = A.cpu().numpy()
+            assert np.max(np.abs(got - want)) <= 1e-13 * max(np.max(np.abs(want)), 1.0)
+            assert np.array_equal(got, got.T)
+        B = torch.as_tensor(mats[rank], device=dev).contiguous()
+        comm.allreduce_sym_(B)
+        got = B.cpu().numpy()
+        assert np.max(np.abs(got - want)) <= 1e-13 * max(np.max(np.abs(want)), 1.0)
+        assert np.array_equal(got, got.T) and getattr(B, "hydra_symmetric", False)
+    comm.barrier()
+
+
 if __name__ == "__main__":
     case = sys.argv[1]
     logdir = sys.argv[2] if len(sys.argv) > 2 else None
@@ -293,7 +447,8 @@ if __name__ == "__main__":
     try:
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
          "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
-         "rowshard": case_rowshard}[case](comm)
+         "rowshard": case_rowshard, "shmpi": case_shmpi, "gainmpi": case_gainmpi,
+         "symreduce": case_symreduce}[case](comm)
     except BaseException:
         import traceback
         if logdir:

@@ -61,7 +61,8 @@ def test_argument_validation_returns_error_codes():
     assert lib.hydra_gram_workspace_bytes(14400, 100) % (128 * 128 * 8) == 0
     assert lib.hydra_cg_state_len() == 776
     assert lib.hydra_symv_workspace_bytes(100, 3) == 3 * 2 * 100 * 8
-    assert lib.hydra_cg_workspace_bytes(100) == (3 * 100 + 776) * 8 + 2 * 100 * 8
+    assert lib.hydra_cg_workspace_bytes(100) == (3 * 100 + 776) * 8       # no symv scratch below 4096
+    assert lib.hydra_cg_workspace_bytes(4096) == (3 * 4096 + 776) * 8 + 64 * 4096 * 8
 
 
 def test_fused_gram_rejects_malformed_tables():
@@ -116,3 +117,20 @@ def test_product_package_does_not_import_the_oracle():
         if fn.endswith(".py"):
             text = open(os.path.join(pkg, fn)).read()
             assert "import oracle" not in text and "from oracle" not in text, fn
+
+
+def test_baseline_index_cache_notices_in_place_edits():
+    ants = np.arange(6)
+    pairs = [(i, j) for i in range(6) for j in range(i + 1, 6)]
+    bi, bj = _tables.baseline_indices(ants, pairs)
+    assert _tables.baseline_indices(ants, pairs)[0] is bi            # cache hit
+    pairs[0], pairs[-1] = pairs[-1], pairs[0]                        # same object, same length
+    bi2, bj2 = _tables.baseline_indices(ants, pairs)
+    assert (bi2[0], bj2[0]) == (4, 5) and (bi2[-1], bj2[-1]) == (0, 1)
+
+
+def test_gain_index_cache_is_bounded():
+    from hydra_amd import gain_sampler as gs
+    for _ in range(3 * gs._INDEX_CACHE_MAX):
+        gs.proj_operator(np.arange(3), [(0, 1), (1, 2)])
+    assert len(gs._INDEX_CACHE) <= gs._INDEX_CACHE_MAX

@@ -72,3 +72,23 @@ def test_freq_sharded_cosmo_system_world3():
 @pytest.mark.gpu
 def test_cg_mpi_world4():
     _run("cgmpi", 4)
+
+
+@pytest.mark.gpu
+def test_sh_head_rows_split_over_ranks_and_root_driven_cg_world2():
+    _run("shmpi", 2)
+
+
+@pytest.mark.gpu
+def test_sh_head_rows_split_over_ranks_world3():
+    _run("shmpi", 3)
+
+
+@pytest.mark.gpu
+def test_gain_head_channels_split_over_ranks_world2():
+    _run("gainmpi", 2)
+
+
+@pytest.mark.gpu
+def test_symmetric_packed_reduce_world3():
+    _run("symreduce", 3)
