@@ -803,6 +803,10 @@ def main():
                     help="auto = closed-form antenna-space Gram when the array is complete and the "
                          "noise weights do not depend on the baseline (true for this workload), "
                          "general = always the per-baseline-weight kernel")
+    ap.add_argument("--flags", type=float, default=0.0,
+                    help="fraction of (baseline, freq, time) samples flagged (inverse noise variance "
+                         "0) at random, plus one dead baseline: the closed-form Gram then takes its "
+                         "flagged-row correction (ptsrc configs)")
     ap.add_argument("--no-general", action="store_true",
                     help="skip the extra launches of the general Gram kernel after the timed region")
     ap.add_argument("--shard", default=None, choices=["freq", "baseline"],
@@ -887,6 +891,9 @@ def main():
                                              generator=gen)
     inv_noise = torch.full((nbl, nf_loc, nt), 1.0 / inp["sigma_noise"] ** 2, dtype=torch.float64,
                            device=dev)
+    if args.flags > 0.0:
+        inv_noise[torch.rand(inv_noise.shape, device=dev, generator=gen) < args.flags] = 0.0
+        inv_noise[nbl // 3] = 0.0
     prior = torch.as_tensor(inp["prior"], device=dev)
     del gg
     m_loc = nbl * nf_loc * nt
@@ -1033,6 +1040,8 @@ def main():
                          + (", gridded beam (bicubic spline)" if big else "")),
             "rows_M": m_all, "solver": args.solver, "cg_abs_tol": args.cg_tol,
             "cg_iters_last": int(iters), "gram": args.gram,
+            "flagged_fraction": args.flags,
+            "flagged_rows_corrected": int(getattr(fac, "last_gram_flagged_rows", 0)),
             "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU",
         },
         # the metric's "Gram FP64 TFLOP/s": baseline-form flops 2 M Ns (Ns+1) over the Gram time,

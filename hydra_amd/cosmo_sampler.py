@@ -203,6 +203,9 @@ def precompute_mpi(comm, ants, antpairs, freqs, freq_chunk, time_chunk, proj_chu
     b = _dev.zeros((freqs_h.size, npix), torch.float64)
     if not factored:
         R_all = _dev.c128(proj_chunk)
+    # one analysis of the noise weights for all channels (cached with the weight tensor)
+    plans = proj_chunk.channel_plans(w) if factored and proj_chunk.complete \
+        and proj_chunk.allow_uniform else None
     for j in range(nfc):
         hit = np.nonzero(freqs_h == fchunk_h[j])[0]          # :279, :325
         if hit.size == 0:
@@ -212,7 +215,7 @@ def precompute_mpi(comm, ants, antpairs, freqs, freq_chunk, time_chunk, proj_chu
         z_j = z[:, j:j + 1, :].contiguous()
         if factored:
             sub = proj_chunk.channel(j)
-            G_j = _timed_gram(lambda: sub.gram(g_j, w_j))
+            G_j = _timed_gram(lambda: sub.gram(g_j, w_j, plan=None if plans is None else plans[j]))
             proj_chunk.last_gram_kernel = sub.last_gram_kernel
             b_j = sub.adjoint(z_j)
         else:

@@ -564,6 +564,88 @@ noise_uniform_kernel(const double* __restrict__ w, int nbl, int nft, double* __r
   if (__any(bad) && (threadIdx.x & 63) == 0) atomicOr(flag, 1);
 }
 
+// ---- closed-form Gram with flagged / down-weighted samples -------------------------------
+// Real data are flagged: a few (b,f,t) samples carry weight 0 (or less than their neighbours).
+// With w_ref[ft] = max_b w[b,ft] the Gram splits exactly into
+//   G = G_closed(all pairs, w_ref) - sum_{(b,ft): w < w_ref} (w_ref[ft] - w[b,ft]) Re(conj(R'_b,ft) R'_b,ft^T),
+// the closed form plus a Gram over the MATERIALISED rows of the deviating samples only
+// (gram_kernel; 1 % flags at config 2 = 85 000 of 8.5 M rows).  Replaces ptsrc_sampler.py:62-75
+// for arbitrary inv_noise_var as long as the deviating samples are few; otherwise the general
+// kernel runs.
+__global__ void __launch_bounds__(256)
+noise_ref_kernel(const double* __restrict__ w, int nbl, int nft, double* __restrict__ wref) {
+  int ft = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ft >= nft) return;
+  double m = w[ft];
+  for (int b = 1; b < nbl; ++b) m = fmax(m, w[(size_t)b * nft + ft]);
+  wref[ft] = m;
+}
+
+// row indices e = b * nft + ft of the samples with w[e] != wref[ft], appended in arbitrary order
+// (the caller sorts them); *count receives their number even beyond `capacity`
+__global__ void __launch_bounds__(256)
+noise_dev_kernel(const double* __restrict__ w, const double* __restrict__ wref, int nbl, int nft,
+                 long long capacity, long long* __restrict__ idx,
+                 unsigned long long* __restrict__ count) {
+  const size_t total = (size_t)nbl * nft;
+  for (size_t e = (size_t)blockIdx.x * blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    if (w[e] != wref[e % nft]) {
+      unsigned long long pos = atomicAdd(count, 1ULL);
+      if ((long long)pos < capacity) idx[pos] = (long long)e;
+    }
+  }
+}
+
+// R[r,:] = conj(V[ft,i_b,:]) V[ft,j_b,:] and rows[r] = g_i conj(g_j) sqrt(wref[ft] - w[b,ft]) for
+// the listed samples r -> e = idx[r] = b * nft + ft
+__global__ void __launch_bounds__(256)
+flagged_rows_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
+                    const f64x2* __restrict__ gains, const double* __restrict__ w,
+                    const double* __restrict__ wref, const int32_t* __restrict__ bl_i,
+                    const int32_t* __restrict__ bl_j, const long long* __restrict__ idx,
+                    long long nrows, f64x2* __restrict__ R, f64x2* __restrict__ rows) {
+  for (long long r = blockIdx.y; r < nrows; r += gridDim.y) {
+    const long long e = idx[r];
+    const int b = (int)(e / nft), ft = (int)(e % nft);
+    const int i = bl_i[b], j = bl_j[b];
+    const f64x2* vi = V + ((size_t)ft * nant + i) * ns;
+    const f64x2* vj = V + ((size_t)ft * nant + j) * ns;
+    f64x2* out = R + (size_t)r * ns;
+    for (int s = blockIdx.x * blockDim.x + threadIdx.x; s < ns; s += gridDim.x * blockDim.x)
+      out[s] = cmul_conj(vi[s], vj[s]);
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+      f64x2 fac = {1.0, 0.0};
+      if (gains) {
+        f64x2 gi = gains[(size_t)i * nft + ft], gj = gains[(size_t)j * nft + ft];
+        gj.y = -gj.y;
+        fac = cmul(gi, gj);
+      }
+      double d = sqrt(fmax(wref[ft] - w[e], 0.0));
+      rows[r] = f64x2{fac.x * d, fac.y * d};
+    }
+  }
+}
+
+// G <- epilogue(G - C) on full symmetric matrices (same operation order on (i,j) and (j,i))
+__global__ void __launch_bounds__(256)
+gram_subtract_kernel(double* __restrict__ G, const double* __restrict__ C, int ns,
+                     const double* __restrict__ prior_std, const double* __restrict__ add_diag) {
+  size_t n = (size_t)ns * ns;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < n;
+       e += (size_t)gridDim.x * blockDim.x) {
+    int i = (int)(e / ns), j = (int)(e % ns);
+    double v = G[e] - C[e];
+    if (prior_std) {
+      v = prior_std[i > j ? i : j] * v * prior_std[i > j ? j : i];
+      if (i == j) v = 1.0 + v;
+    } else if (add_diag && i == j) {
+      v += add_diag[i];
+    }
+    G[e] = v;
+  }
+}
+
 // ---- 3-product form of the closed-form Gram ---------------------------------------------
 // T = sum_a u_s conj(u_s') needs Re T = X^T X' + Y^T Y' and Im T = Y^T X' - X^T Y' (u = x + i y).
 // With P1 = X^T X', P2 = Y^T Y', P3 = (X+Y)^T (X'-Y') = P1 - P2 + Im T:
@@ -904,6 +986,51 @@ int hydra_gram(const double* R, const double* rows, long long m, int ns, const d
   gram_finish_kernel<<<ntiles, 256, 0, as_stream(stream)>>>(slabs, nsplit, ntiles, ns, prior_std,
                                                             add_diag, G);
   HYDRA_CHECK_LAUNCH("hydra_gram(finish)");
+  return HYDRA_OK;
+}
+
+int hydra_noise_deviations(const double* inv_noise, int nbl, int nf, int nt, double* w_ref,
+                           long long* idx, long long capacity, unsigned long long* count_dev,
+                           void* stream) {
+  HYDRA_CHECK_ARG(inv_noise && w_ref && count_dev && nbl > 0 && nf > 0 && nt > 0 && capacity >= 0 &&
+                      (idx || capacity == 0),
+                  "hydra_noise_deviations: bad arguments");
+  hipStream_t st = as_stream(stream);
+  int nft = nf * nt;
+  hipError_t e = hipMemsetAsync(count_dev, 0, sizeof(unsigned long long), st);
+  if (e != hipSuccess)
+    return fail(HYDRA_ERR_HIP, "hydra_noise_deviations: %s", hipGetErrorString(e));
+  noise_ref_kernel<<<(nft + 255) / 256, 256, 0, st>>>(inv_noise, nbl, nft, w_ref);
+  size_t total = (size_t)nbl * nft;
+  int grid = (int)std::min<size_t>((total + 255) / 256, 8192);
+  noise_dev_kernel<<<grid, 256, 0, st>>>(inv_noise, w_ref, nbl, nft, capacity, idx, count_dev);
+  HYDRA_CHECK_LAUNCH("hydra_noise_deviations");
+  return HYDRA_OK;
+}
+
+int hydra_flagged_rows(const double* V, int nf, int nt, int nant, int ns, const double* gains,
+                       const double* inv_noise, const double* w_ref, const int32_t* bl_i,
+                       const int32_t* bl_j, int nbl, const long long* idx, long long nrows,
+                       double* R, double* rows, void* stream) {
+  HYDRA_CHECK_ARG(V && inv_noise && w_ref && bl_i && bl_j && idx && R && rows && nf > 0 && nt > 0 &&
+                      nant > 0 && ns > 0 && nbl > 0 && nrows > 0,
+                  "hydra_flagged_rows: bad arguments");
+  dim3 grid(std::min((ns + 255) / 256, 64), (unsigned)std::min<long long>(nrows, 65535));
+  flagged_rows_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+      reinterpret_cast<const f64x2*>(V), nf * nt, nant, ns, reinterpret_cast<const f64x2*>(gains),
+      inv_noise, w_ref, bl_i, bl_j, idx, nrows, reinterpret_cast<f64x2*>(R),
+      reinterpret_cast<f64x2*>(rows));
+  HYDRA_CHECK_LAUNCH("hydra_flagged_rows");
+  return HYDRA_OK;
+}
+
+int hydra_gram_subtract(double* G, const double* C, int ns, const double* prior_std,
+                        const double* add_diag, void* stream) {
+  HYDRA_CHECK_ARG(G && C && ns > 0 && !(prior_std && add_diag), "hydra_gram_subtract: bad arguments");
+  size_t n = (size_t)ns * ns;
+  int grid = (int)std::min<size_t>((n + 255) / 256, 4096);
+  gram_subtract_kernel<<<grid, 256, 0, as_stream(stream)>>>(G, C, ns, prior_std, add_diag);
+  HYDRA_CHECK_LAUNCH("hydra_gram_subtract");
   return HYDRA_OK;
 }
 

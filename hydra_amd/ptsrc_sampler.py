@@ -119,32 +119,113 @@ class FactoredProj:
                   _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
         return out
 
-    def gram(self, gains, inv_noise, prior_std=None, add_diag=None):
+    #: the closed form + flagged-row correction is taken while the deviating samples are at most
+    #: this fraction of all rows and their materialised rows fit this many bytes
+    FLAG_MAX_FRACTION = 0.10
+    FLAG_MAX_BYTES = 24 << 30
+
+    def _noise_plan(self, inv_noise):
+        """How the noise weights enter the Gram: ("uniform", w_ft) -- the same for all baselines
+        of an (f,t) sample; ("flagged", w_ref, idx) -- a few samples (flags) below the common
+        weight w_ref[f,t], idx their sorted flat indices; ("general",) otherwise.
+        The analysis reads one counter back to the host, so it is done once per weight tensor and
+        cached (key: storage address + torch's in-place version counter, the tensor kept alive);
+        the Gibbs loop passes the same inv_noise_var every iteration (example.py:878-889)."""
+        nf, nt, nant, ns = self.V.shape
+        nbl = self.shape[0]
+        key = (inv_noise.data_ptr(), inv_noise._version, tuple(inv_noise.shape))
+        hit = getattr(self, "_plan_cache", None)
+        if hit is not None and hit[0] == key and hit[1] is inv_noise:
+            return hit[2]
+        m = nbl * nf * nt
+        cap = int(min(self.FLAG_MAX_FRACTION * m, self.FLAG_MAX_BYTES // (16 * ns)))
+        w_ref = _dev.empty((nf * nt,), torch.float64)
+        idx = torch.empty(max(cap, 1), dtype=torch.int64, device=w_ref.device)
+        count = torch.zeros(1, dtype=torch.int64, device=w_ref.device)
+        _dev.call("hydra_noise_deviations", _dev.ptr(inv_noise), nbl, nf, nt, _dev.ptr(w_ref),
+                  _dev.ptr(idx), cap, _dev.ptr(count), _dev.stream_ptr())
+        n_dev = int(count.item())
+        if n_dev == 0:
+            plan = ("uniform", w_ref)
+        elif n_dev <= cap:
+            plan = ("flagged", w_ref, torch.sort(idx[:n_dev]).values.contiguous())
+        else:
+            plan = ("general",)
+        self._plan_cache = (key, inv_noise, plan)
+        return plan
+
+    def channel_plans(self, inv_noise):
+        """``_noise_plan`` of every frequency channel taken alone (for ``channel(j).gram(...,
+        plan=plans[j])``), derived from ONE analysis of the whole weight tensor and cached with
+        it -- a head that builds one Gram per channel (cosmo_sampler.py:276-284) would otherwise
+        read a counter back per channel and sample."""
+        plan = self._noise_plan(inv_noise)
+        hit = getattr(self, "_chan_plan_cache", None)
+        if hit is not None and hit[0] is plan:
+            return hit[1]
+        nf, nt = self.V.shape[0], self.V.shape[1]
+        if plan[0] == "general":
+            plans = [plan] * nf
+        elif plan[0] == "uniform":
+            plans = [("uniform", plan[1][j * nt:(j + 1) * nt]) for j in range(nf)]
+        else:
+            idx = plan[2]
+            b, rem = idx // (nf * nt), idx % (nf * nt)
+            f, t = rem // nt, rem % nt
+            plans = []
+            for j in range(nf):
+                sel = f == j
+                wr = plan[1][j * nt:(j + 1) * nt]
+                ij = (b[sel] * nt + t[sel]).contiguous()
+                plans.append(("flagged", wr, ij) if ij.numel() else ("uniform", wr))
+        self._chan_plan_cache = (plan, plans)
+        return plans
+
+    def gram(self, gains, inv_noise, prior_std=None, add_diag=None, plan=None):
         """Re(R'^H N^-1 R') on the FP64 matrix cores, R' = diag(g_i conj g_j) R.
 
         General form: rank-Nbl update per (f,t) with per-baseline weights (gram_fused_kernel).
         If the array is complete and the weights do not depend on the baseline, the exact
-        closed form in the antenna voltages is used instead (gram_uniform_kernel)."""
+        closed form in the antenna voltages is used instead (gram_uniform_kernel); if a few
+        samples are flagged (weight below the common one of their (f,t)), the closed form is
+        corrected by a Gram over the materialised rows of those samples."""
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
+        st = _dev.stream_ptr()
         if self.complete and self.allow_uniform and nant > 1:
-            w_ft = None
-            uniform = True
-            if inv_noise is not None:
-                w_ft = _dev.empty((nf * nt,), torch.float64)
-                flag = _dev.zeros((1,), torch.int32)
-                _dev.call("hydra_noise_uniformity", _dev.ptr(inv_noise), nbl, nf, nt,
-                          _dev.ptr(w_ft), _dev.ptr(flag), _dev.stream_ptr())
-                uniform = int(flag.item()) == 0
-            if uniform:
+            if plan is None:
+                plan = ("uniform", None) if inv_noise is None else self._noise_plan(inv_noise)
+            if plan[0] != "general":
+                flagged = plan[0] == "flagged"
                 nbytes = _dev._lib.query("hydra_gram_uniform_workspace_bytes", nf, nt, nant, ns)
                 ws = _dev.workspace(nbytes)
                 G = _dev.empty((ns, ns), torch.float64)
                 _dev.call("hydra_gram_uniform", _dev.ptr(self.V), nf, nt, nant, ns,
-                          _dev.ptr(gains), _dev.ptr(w_ft), int(self.same_beam), _dev.ptr(prior_std),
-                          _dev.ptr(add_diag), _dev.ptr(G), _dev.ptr(ws), ws.numel(),
-                          _dev.stream_ptr())
+                          _dev.ptr(gains), _dev.ptr(plan[1]), int(self.same_beam),
+                          _dev.ptr(None if flagged else prior_std),
+                          _dev.ptr(None if flagged else add_diag), _dev.ptr(G), _dev.ptr(ws),
+                          ws.numel(), st)
                 self.last_gram_kernel = "gram_uniform_kernel"
+                self.last_gram_flagged_rows = 0
+                if flagged:
+                    del ws
+                    # a timing bracket set by _timed_gram stays on the closed-form kernel
+                    _dev.call("hydra_profile_events", _dev.ptr(None), _dev.ptr(None))
+                    idx = plan[2]
+                    nrows = int(idx.numel())
+                    R = _dev.empty((nrows, ns), torch.complex128)
+                    rows = _dev.empty((nrows,), torch.complex128)
+                    _dev.call("hydra_flagged_rows", _dev.ptr(self.V), nf, nt, nant, ns,
+                              _dev.ptr(gains), _dev.ptr(inv_noise), _dev.ptr(plan[1]),
+                              _dev.ptr(self.bl_i), _dev.ptr(self.bl_j), nbl, _dev.ptr(idx), nrows,
+                              _dev.ptr(R), _dev.ptr(rows), st)
+                    ws2 = _dev.workspace(_dev._lib.query("hydra_gram_workspace_bytes", nrows, ns))
+                    C = _dev.empty((ns, ns), torch.float64)
+                    _dev.call("hydra_gram", _dev.ptr(R), _dev.ptr(rows), nrows, ns, _dev.ptr(None),
+                              _dev.ptr(None), _dev.ptr(C), _dev.ptr(ws2), ws2.numel(), st)
+                    _dev.call("hydra_gram_subtract", _dev.ptr(G), _dev.ptr(C), ns,
+                              _dev.ptr(prior_std), _dev.ptr(add_diag), st)
+                    self.last_gram_flagged_rows = nrows
                 return G
         self.last_gram_kernel = "gram_fused_kernel"
         nbytes = _dev._lib.query("hydra_gram_fused_workspace_bytes", nf, nt, nbl, ns)
@@ -155,7 +236,7 @@ class FactoredProj:
                   _dev.host_ptr(self.rowtab_host), _dev.ptr(self.seg), _dev.ptr(self.rowtab),
                   int(self.seg_host.shape[0]), int(self.rowtab_host.shape[0]),
                   _dev.ptr(prior_std), _dev.ptr(add_diag), _dev.ptr(G), _dev.ptr(ws), ws.numel(),
-                  _dev.stream_ptr())
+                  st)
         return G
 
 

@@ -200,6 +200,27 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
                        const double* add_diag, double* G, void* workspace, size_t workspace_bytes,
                        void* stream);
 
+/* Closed-form Gram for FLAGGED data (arbitrary inv_noise_var of ptsrc_sampler.py:62-75 as long as few
+ * samples deviate): with w_ref[f,t] = max_b inv_noise[b,f,t],
+ *   G = G_closed(all pairs, w_ref) - sum_{(b,f,t): w < w_ref} (w_ref - w) Re(conj(R'_bft) R'_bft^T),
+ * i.e. hydra_gram_uniform(w_ft = w_ref, no epilogue) minus hydra_gram over the materialised rows of
+ * the deviating samples, combined by hydra_gram_subtract (which applies the epilogue).
+ *   hydra_noise_deviations: fills w_ref (Nf*Nt) and appends the flat indices e = b*Nf*Nt + ft of the
+ *     samples with inv_noise[e] != w_ref[ft] to idx (int64, arbitrary order, at most `capacity`);
+ *     *count_dev (device uint64) receives their total number, which may exceed capacity.
+ *   hydra_flagged_rows: for the listed samples, R (nrows,Ns) c128 = conj(V_i) V_j and
+ *     rows (nrows) c128 = g_i conj(g_j) sqrt(w_ref - w) -- the operands of hydra_gram.
+ *   hydra_gram_subtract: G <- epilogue(G - C), epilogues as hydra_gram (ptsrc_sampler.py:91-94).   */
+int hydra_noise_deviations(const double* inv_noise, int nbl, int nf, int nt, double* w_ref,
+                           long long* idx, long long capacity, unsigned long long* count_dev,
+                           void* stream);
+int hydra_flagged_rows(const double* V, int nf, int nt, int nant, int ns, const double* gains,
+                       const double* inv_noise, const double* w_ref, const int32_t* bl_i,
+                       const int32_t* bl_j, int nbl, const long long* idx, long long nrows,
+                       double* R, double* rows, void* stream);
+int hydra_gram_subtract(double* G, const double* C, int ns, const double* prior_std,
+                        const double* add_diag, void* stream);
+
 /* Profiling hook: HIP events (hipEvent_t, NULL to clear) recorded by this thread's next calls of
  * hydra_gram_fused / hydra_gram_uniform on their stream immediately before and after the main
  * Gram kernel.  No counterpart in the reference.                                            */
