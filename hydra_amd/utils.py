@@ -100,6 +100,40 @@ def freqs_times_for_worker(comm, freqs, times, fchunks, tchunks=1):
     return fsplit[fi], tsplit[ti], worker_map
 
 
+def convert_to_tops(ra, dec, lsts, latitude, precision=1):
+    """Topocentric direction cosines (l, m, n) = (east, north, up) of the directions (ra, dec)
+    at the given LSTs from ``latitude`` (utils.py:422-458): three arrays (Nt, Nsrc).  The
+    equatorial unit vectors and the ECI->ENU matrices come from the same device kernels the
+    simulator uses (hydra_crd_eq / hydra_eq2tops = matvis.coordinates.point_source_crd_eq /
+    eci_to_enu_matrix); as in the reference, ``precision=1`` rounds the matrices (not the unit
+    vectors) to float32 before the product."""
+    ra_d, dec_d = _dev.f64(np.atleast_1d(ra)), _dev.f64(np.atleast_1d(dec))
+    lsts_d = _dev.f64(np.atleast_1d(lsts))
+    ns, nt = ra_d.numel(), lsts_d.numel()
+    crd_eq = _dev.empty((3, ns), torch.float64)
+    eq2tops = _dev.empty((nt, 3, 3), torch.float64)
+    _dev.call("hydra_crd_eq", _dev.ptr(ra_d), _dev.ptr(dec_d), ns, _dev.ptr(crd_eq),
+              _dev.stream_ptr())
+    _dev.call("hydra_eq2tops", _dev.ptr(lsts_d), nt, float(latitude), _dev.ptr(eq2tops),
+              _dev.stream_ptr())
+    real_dtype = np.float32 if precision == 1 else np.float64
+    crd = crd_eq.cpu().numpy()
+    mats = eq2tops.cpu().numpy().astype(real_dtype)
+    tops = np.array([np.dot(m, crd) for m in mats])          # (Nt, 3, Nsrc)
+    return tops[:, 0], tops[:, 1], tops[:, 2]
+
+
+def get_beam_interp_shape(beam):
+    """Whether a beam object's ``interp`` return carries the (old pyuvdata) spectral-window axis
+    (utils.py:542-562): False for analytic beams and beam interfaces, ``not
+    beam.future_array_shapes`` for UVBeam-like objects, False for anything else."""
+    if hasattr(beam, "compute_response") and not hasattr(beam, "future_array_shapes"):
+        return False
+    if hasattr(beam, "future_array_shapes"):
+        return not beam.future_array_shapes
+    return False
+
+
 def build_hex_array(hex_spec=(3, 4), ants_per_row=None, d=14.6):
     """Antenna dict {id: (x, y, 0.)} of a hexagonally packed array (utils.py:374-419)."""
     if ants_per_row is None:

@@ -45,3 +45,10 @@ def elem_err(a, b, rtol=1e-10, floor=1e-13):
     if scale == 0.0:
         return float(np.max(np.abs(a))) if a.size else 0.0
     return float(np.max(np.abs(a - b) / (rtol * np.abs(b) + floor * scale)))
+
+
+def operr(a, b, rtol=1e-10, floor=1e-13):
+    """Parity measure for operator entries, to be compared with 1e-10: the larger of the max-norm
+    relative error and ``rtol`` times the element-wise measure -- i.e. ``operr < 1e-10`` demands
+    BOTH max|a-b| < 1e-10 max|b| and |a-b| <= 1e-10 |b| + 1e-13 max|b| for every entry."""
+    return max(relerr(a, b), rtol * elem_err(a, b, rtol=rtol, floor=floor))

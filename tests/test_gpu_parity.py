@@ -4,12 +4,12 @@ CPU oracle on identical seeded inputs and injected fluctuation vectors, and agai
 vectors produced by the reference itself (tests/golden/).
 
 Tolerances (BASELINE.json north_star): operator entries <= 1e-10 relative (FP64); GCR samples
-<= 1e-8 relative.  "Relative" is max|a-b| / max|b| over the array.
+<= 1e-8 relative.  The operator checks use conftest.operr: max-norm relative error AND every entry within 1e-10 |b| + 1e-13 max|b|.
 """
 import numpy as np
 import pytest
 
-from conftest import load_golden, relerr
+from conftest import load_golden, operr, relerr
 
 pytestmark = pytest.mark.gpu
 
@@ -96,18 +96,18 @@ def test_per_source_cube_matches_oracle(hy, orc):
                                                    bh, latitude=LAT)
     assert got.shape == ref.shape and got.dtype == np.complex128
     assert np.count_nonzero(ref) > 0 and np.any(ref == 0)       # sources above and below horizon
-    assert relerr(got, ref) < OP_TOL
+    assert operr(got, ref) < OP_TOL
     # lower triangle left at zero, autos populated (vis_simulator.py:281-289)
     assert np.all(got[:, :, 3, 1] == 0) and np.any(got[:, :, 2, 2] != 0)
     # sum over sources (simulate_vis) and the subarr_ant variant
     tot = hy.vis_simulator.simulate_vis(ant_pos, fluxes, ra, dec, freqs * 1e6, times, bh,
                                         latitude=LAT)
-    assert relerr(tot, ref.sum(axis=-1)) < OP_TOL
+    assert operr(tot, ref.sum(axis=-1)) < OP_TOL
     sub = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
                                                    bh, latitude=LAT, subarr_ant=2)
     subref = orc.response.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
                                                   bo, latitude=LAT, subarr_ant=2)
-    assert relerr(sub, subref) < OP_TOL
+    assert operr(sub, subref) < OP_TOL
 
 
 def test_vis_sim_per_source_single_channel_and_beam_variants(hy, orc):
@@ -128,20 +128,20 @@ def test_vis_sim_per_source_single_channel_and_beam_variants(hy, orc):
         ref = orc.response.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], bo)
         got = hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], bh)
         assert got.shape == (times.size, len(ant_pos), len(ant_pos), ra.size)
-        assert relerr(got, ref) < OP_TOL
+        assert operr(got, ref) < OP_TOL
     # a beam object without an in-kernel form goes through compute_response on the host
     class HostBeam(orc.beams.GaussianBeam):
         pass
     hb = [HostBeam(diameter=14.0)]
     ref = orc.response.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], hb)
     got = hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0], hb)
-    assert relerr(got, ref) < OP_TOL
+    assert operr(got, ref) < OP_TOL
     # force_no_beam_sqrt
     ref = orc.response.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
                                           cases[0][0], force_no_beam_sqrt=True)
     got = hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
                                               cases[0][1], force_no_beam_sqrt=True)
-    assert relerr(got, ref) < OP_TOL
+    assert operr(got, ref) < OP_TOL
     # error behaviour of the reference: wrong beam count, NaN beam, shape asserts
     with pytest.raises(ValueError):
         hy.vis_simulator.vis_sim_per_source(antpos, 1.1e8, eq2tops, crd_eq, fluxes[:, 0],
@@ -168,12 +168,12 @@ def test_calc_proj_operator_matches_oracle(hy, orc):
     ref = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
     got = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh)
     assert got.shape == (45, 4, 5, 50)
-    assert relerr(got, ref) < OP_TOL
+    assert operr(got, ref) < OP_TOL
     # a pair listed against dict order picks up the zero lower triangle, as in the reference
     ap2 = [(1, 0)] + antpairs[1:]
     got2 = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, ap2, freqs, times, bh)
     ref2 = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, ap2, freqs, times, bo)
-    assert np.all(got2[0] == 0) and relerr(got2, ref2) < OP_TOL
+    assert np.all(got2[0] == 0) and operr(got2, ref2) < OP_TOL
     # reference smoke test (hydra/tests/test_ptsrc_sampler.py): 3 antennas, 17 sources
     np.random.seed(3)
     ant3 = {0: (0.0, 0.0, 0.0), 1: (0.0, 14.0, 0.0), 2: (0.0, 0.0, 14.0)}
@@ -188,7 +188,7 @@ def test_calc_proj_operator_matches_oracle(hy, orc):
     assert np.all(~np.isnan(proj))
     ref3 = orc.ptsrc.calc_proj_operator(ra3, dec3, fl3, ant3, ap3, fr, lsts,
                                         [orc.beams.GaussianBeam(diameter=14.0)] * 3)
-    assert relerr(proj, ref3) < OP_TOL
+    assert operr(proj, ref3) < OP_TOL
     data = (proj.reshape((-1, 17)) @ np.ones(17)).reshape(3, 10, 5)
     A, b = hy.ptsrc_sampler.precompute_mpi(
         comm=None, ants=list(ant3.keys()), antpairs=ap3, freq_chunk=fr, time_chunk=lsts,
@@ -208,19 +208,19 @@ def test_precompute_matches_reference_golden(hy, name):
     A, b = hy.ptsrc_sampler.precompute_mpi(
         None, g["ants"], ap, np.arange(nf), np.arange(nt), g["proj"], g["data"], g["inv_noise"],
         g["gains"], g["prior"], realisation=True, omega_n=g["omega_n"], omega_a=g["omega_a"])
-    assert relerr(A, g["A"]) < OP_TOL
-    assert relerr(b, g["b"]) < OP_TOL
+    assert operr(A, g["A"]) < OP_TOL
+    assert operr(b, g["b"]) < OP_TOL
     assert np.array_equal(A, A.T)
     # drawing omega from the global RNG in the reference's order reproduces the reference
     np.random.seed(int(g["seed"]))
     A2, b2 = hy.ptsrc_sampler.precompute_mpi(
         None, g["ants"], ap, np.arange(nf), np.arange(nt), g["proj"], g["data"], g["inv_noise"],
         g["gains"], g["prior"], realisation=True)
-    assert relerr(b2, g["b"]) < OP_TOL
+    assert operr(b2, g["b"]) < OP_TOL
     A0, b0 = hy.ptsrc_sampler.precompute_mpi(
         None, g["ants"], ap, np.arange(nf), np.arange(nt), g["proj"], g["data"], g["inv_noise"],
         g["gains"], g["prior"], realisation=False)
-    assert relerr(A0, g["A0"]) < OP_TOL and relerr(b0, g["b0"]) < OP_TOL
+    assert operr(A0, g["A0"]) < OP_TOL and operr(b0, g["b0"]) < OP_TOL
     # samples: CG and the dense fallback against the reference's dense solve of its own system
     import scipy.linalg
     xref = scipy.linalg.solve(g["A"], g["b"], assume_a="her")
@@ -246,11 +246,12 @@ def _gcr_inputs(nbl, nant, nf, nt, ns, seed, uniform_noise=False):
 
 
 @pytest.mark.parametrize("hex_spec,ns,nf,nt", [((3, 4), 100, 4, 5), ((4, 7), 150, 2, 3),
-                                               ((5, 9), 200, 2, 2)])
+                                               ((5, 9), 200, 2, 2), ((3, 4), 100, 16, 20)])
 def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, nf, nt):
     """End to end on the simulator's own operator: fused (factored) path == materialised HIP
     path == oracle, for one-segment (10, 37 antennas) and multi-segment (61 antennas) tables;
-    Ns not a multiple of the 128 tile, odd row counts."""
+    Ns not a multiple of the 128 tile, odd row counts.  The last case is BASELINE config 1 at
+    its exact size: hex (3,4) = 10 antennas / 45 baselines, 100 sources, 16 freqs, 20 times."""
     ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(hex_spec, ns, nf, nt, seed=5)
     nant, nbl = len(ant_pos), len(antpairs)
     ants = np.array(list(ant_pos.keys()))
@@ -270,7 +271,7 @@ def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, 
     if nant > 37:
         assert fac.seg_host.shape[0] > 1
     R = fac.materialize().cpu().numpy()
-    assert relerr(R, proj_ref) < OP_TOL
+    assert operr(R, proj_ref) < OP_TOL
     args = (None, ants, antpairs, freqs, times)
     kw = dict(data_chunk=data, inv_noise_var_chunk=inv_noise, gain_chunk=gains,
               amp_prior_std=prior, omega_n=om_n, omega_a=om_a)
@@ -278,12 +279,12 @@ def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, 
     assert fac.last_gram_kernel == "gram_fused_kernel"      # per-baseline weights: general kernel
     A_m, b_m = hy.ptsrc_sampler.precompute_mpi(*args, proj_chunk=R, **kw)
     for A, b in ((A_f, b_f), (A_m, b_m)):
-        assert relerr(A, A_ref) < OP_TOL
-        assert relerr(b, b_ref) < OP_TOL
+        assert operr(A, A_ref) < OP_TOL
+        assert operr(b, b_ref) < OP_TOL
     # model update (example.py:974-976) in both forms
     mod_ref = (proj_ref.reshape(-1, ns) @ truth).reshape(nbl, nf, nt)
-    assert relerr(hy.ptsrc_sampler.apply_proj(R, truth), mod_ref) < OP_TOL
-    assert relerr(hy.ptsrc_sampler.apply_proj(fac, truth).cpu().numpy(), mod_ref) < OP_TOL
+    assert operr(hy.ptsrc_sampler.apply_proj(R, truth), mod_ref) < OP_TOL
+    assert operr(hy.ptsrc_sampler.apply_proj(fac, truth).cpu().numpy(), mod_ref) < OP_TOL
     # the sample
     x_ref = orc.ptsrc.dense_solve(A_ref, b_ref)
     x = hy.linear_solver.cg(A_f, b_f, maxiters=2000, abs_tol=1e-9)
@@ -431,20 +432,20 @@ def test_sh_response_operator_matches_oracle(hy, orc):
     ems, ells, idx = hy.sh_sampler.get_em_ell_idx(lmax)
     assert pg.shape == (6 * freqs.size * lsts.size, len(ems)) and ag.shape[0] == 4 * 6
     assert np.array_equal(ell, ell_r) and np.array_equal(m, m_r)
-    assert relerr(pg, pr) < OP_TOL and relerr(ag, ar) < OP_TOL
+    assert operr(pg, pr) < OP_TOL and operr(ag, ar) < OP_TOL
     assert not np.allclose(pg.imag, 0)
     # include_autos / autos_only variants return 3-tuples
     p2, _, _ = hy.sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside,
                                                       include_autos=True)
     r2, _, _ = orc.sh.vis_proj_operator_no_rot(freqs, lsts, bo, ant_pos, lmax, nside,
                                                include_autos=True)
-    assert p2.shape == r2.shape and relerr(p2, r2) < OP_TOL
+    assert p2.shape == r2.shape and operr(p2, r2) < OP_TOL
     # the raw simulate_vis_per_alm cube (2*nalm modes, zero lower triangle)
     e3, m3, cube = hy.vis_simulator.simulate_vis_per_alm(lmax, nside, ant_pos, freqs * 1e6, lsts, bh,
                                                          latitude=-0.5361913261514378)
     e4, m4, cube_r = orc.response.simulate_vis_per_alm(lmax, nside, ant_pos, freqs * 1e6, lsts, bo,
                                                        latitude=-0.5361913261514378)
-    assert cube.shape == cube_r.shape and relerr(cube, cube_r) < OP_TOL
+    assert cube.shape == cube_r.shape and operr(cube, cube_r) < OP_TOL
 
 
 def test_sh_algebra_matches_reference_golden(hy, orc):
@@ -455,20 +456,20 @@ def test_sh_algebra_matches_reference_golden(hy, orc):
     rhs = hy.sh_sampler.construct_rhs_no_rot(g["data"].flatten(), g["inv_noise"].flatten(),
                                              g["inv_prior"], g["omega_a"], g["omega_n"].flatten(),
                                              g["a0"], g["R"])
-    assert relerr(rhs, g["rhs"]) < OP_TOL
+    assert operr(rhs, g["rhs"]) < OP_TOL
     rhs2 = hy.sh_sampler.construct_rhs_no_rot_mpi(None, g["data"], g["inv_noise"], g["inv_prior"],
                                                   g["omega_a"].copy(), g["omega_n"], g["a0"], g["R"])
-    assert relerr(rhs2, g["rhs_mpi"]) < OP_TOL
+    assert operr(rhs2, g["rhs_mpi"]) < OP_TOL
     lhs = hy.sh_sampler.apply_lhs_no_rot(g["acr"], g["inv_noise"].flatten(), g["inv_prior"], g["R"])
-    assert relerr(lhs, g["lhs"]) < OP_TOL
+    assert operr(lhs, g["lhs"]) < OP_TOL
     lhs2 = hy.sh_sampler.apply_lhs_no_rot_mpi(None, g["acr"].copy(), g["inv_noise"],
                                               g["inv_prior"], g["R"])
-    assert relerr(lhs2, g["lhs_mpi"]) < OP_TOL
+    assert operr(lhs2, g["lhs_mpi"]) < OP_TOL
     assert np.array_equal(hy.sh_sampler.alms2healpy(g["packed"], lmax), g["hp_modes"])
     assert np.array_equal(hy.sh_sampler.healpy2alms(g["hp_modes"]), g["packed"])
     # explicit operator (Gram once) reproduces the matrix-free apply
     A = hy.sh_sampler.lhs_matrix(g["inv_noise"], g["inv_prior"], g["R"])
-    assert relerr(A @ g["acr"], g["lhs"]) < OP_TOL
+    assert operr(A @ g["acr"], g["lhs"]) < OP_TOL
     # the GCR sample: CG with the matrix-free operator (the driver's call, example.py:1045-1052)
     # and with the explicit matrix, against the reference's own CG solution
     x = hy.linear_solver.cg(
@@ -492,24 +493,24 @@ def test_gain_head_matches_reference_golden(hy):
     A_real, A_imag = gs.proj_operator(g["ants"], ap)
     assert np.array_equal(np.asarray(A_real.todense()), g["A_real"])
     assert np.array_equal(np.asarray(A_imag.todense()), g["A_imag"])
-    assert relerr(gs.apply_proj(g["x"], A_real, A_imag, g["mv"]), g["vproj"]) < OP_TOL
-    assert relerr(gs.apply_proj_conj(g["vv"], A_real, A_imag, g["mv"], g["x"].shape),
+    assert operr(gs.apply_proj(g["x"], A_real, A_imag, g["mv"]), g["vproj"]) < OP_TOL
+    assert operr(gs.apply_proj_conj(g["vv"], A_real, A_imag, g["mv"], g["x"].shape),
                   g["gconj"]) < OP_TOL
     # projectors handed over as plain dense arrays (not made by proj_operator) work too
-    assert relerr(gs.apply_proj(g["x"], g["A_real"], g["A_imag"], g["mv"]), g["vproj"]) < OP_TOL
+    assert operr(gs.apply_proj(g["x"], g["A_real"], g["A_imag"], g["mv"]), g["vproj"]) < OP_TOL
     opx = gs.apply_operator_mpi(None, g["xvec"], g["inv_noise"], g["ps_sqrt"], A_real, A_imag,
                                 g["mv"], g["Fb"])
-    assert relerr(opx, g["opx"]) < OP_TOL
+    assert operr(opx, g["opx"]) < OP_TOL
     # the reference's own draws (seeded inside construct_rhs_mpi) ...
     b = gs.construct_rhs_mpi(None, g["resid"], g["inv_noise"], g["ps_sqrt"], A_real, A_imag,
                              g["mv"], g["Fb"], realisation=True, seed=int(g["seed"]))
-    assert relerr(b, g["bvec"]) < OP_TOL
+    assert operr(b, g["bvec"]) < OP_TOL
     # ... and the same vectors injected
     nant, nmodes = g["x"].shape[0], g["Fb"].shape[0]
     om_y, om_r = gcr_gain.draw_gain_omegas(int(g["seed"]), nant, nmodes, g["resid"].shape)
     b2 = gs.construct_rhs_mpi(None, g["resid"], g["inv_noise"], g["ps_sqrt"], A_real, A_imag,
                               g["mv"], g["Fb"], omega_y=om_y, omega_r=om_r)
-    assert relerr(b2, g["bvec"]) < OP_TOL
+    assert operr(b2, g["bvec"]) < OP_TOL
 
 
 @pytest.mark.parametrize("hex_spec,nf,nt,nmax,nvec", [((3, 4), 7, 5, 2, 3), ((4, 7), 16, 12, 3, 9)])
@@ -543,7 +544,7 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
     Y = op.apply(X)
     for v in range(nvec):
         ref = gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)
-        assert relerr(Y[v], ref) < OP_TOL
+        assert operr(Y[v], ref) < OP_TOL
     assert relerr(op.apply(X[0]), Y[0]) < 1e-14                             # single-vector path
     op.tiled = False                                                        # CSR adjacency kernel
     assert relerr(op.apply(X), Y) < 1e-13
@@ -554,7 +555,7 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
     om_y, om_r = gcr_gain.draw_gain_omegas(5, nant, nmodes, resid.shape)
     b_ref = gcr_gain.construct_rhs(resid, w, ps, i1, i2, mv, Fb, om_y, om_r)
     b = gs.construct_rhs_mpi(None, resid, w, ps, A_real, A_imag, mv, Fb, seed=5)
-    assert relerr(b, b_ref) < OP_TOL
+    assert operr(b, b_ref) < OP_TOL
     x = hy.linear_solver.cg(None, b, maxiters=2000, abs_tol=1e-11, use_norm_tol=True,
                             linear_op=op.apply)
     Aref = np.column_stack([gcr_gain.apply_operator(e, w, ps, i1, i2, mv, Fb) for e in np.eye(n)])
@@ -644,22 +645,22 @@ def test_uniform_weight_gram_matches_oracle_and_general_kernel(hy, orc, nant, ns
     A_u, b_u = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
                                                inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
     assert fac.last_gram_kernel == "gram_uniform_kernel"
-    assert relerr(A_u, A_ref) < OP_TOL and relerr(b_u, b_ref) < OP_TOL
+    assert operr(A_u, A_ref) < OP_TOL and operr(b_u, b_ref) < OP_TOL
     assert np.array_equal(A_u, A_u.T)
     fac.allow_uniform = False
     A_g, _ = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
                                              inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
     assert fac.last_gram_kernel == "gram_fused_kernel"
     assert relerr(A_u, A_g) < 1e-12
-    # one baseline with a different weight: the closed form does not apply and must not be taken
+    # one baseline with a different weight: the closed form takes its one-row correction
     fac.allow_uniform = True
     inv_noise[3, 0, 0] *= 0.5
     A_ref2, _ = orc.ptsrc.precompute(ants, antpairs, proj_ref, data, inv_noise, gains, prior,
                                      omega_n=om_n, omega_a=om_a)
     A_2, _ = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
                                              inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
-    assert fac.last_gram_kernel == "gram_fused_kernel"
-    assert relerr(A_2, A_ref2) < OP_TOL
+    assert fac.last_gram_kernel == "gram_uniform_kernel" and fac.last_gram_flagged_rows == 1
+    assert operr(A_2, A_ref2) < OP_TOL
     # an incomplete array (one pair missing) never takes it
     fac2 = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs[:-1], freqs,
                                                times, bh, materialize=False)
@@ -713,7 +714,7 @@ def test_simulator_with_gridded_beams_matches_oracle(hy, orc):
                                                    beams_o, latitude=LAT)
         got = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6,
                                                        times, beams_h, latitude=LAT)
-        assert relerr(got, ref) < OP_TOL
+        assert operr(got, ref) < OP_TOL
 
 
 def test_large_array_factored_operator_matches_oracle(hy, orc):
@@ -743,10 +744,10 @@ def test_large_array_factored_operator_matches_oracle(hy, orc):
     assert fac.seg_host.shape[0] == 45
     A, b = hy.ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, fac, data,
                                            inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
-    assert relerr(A, A_ref) < OP_TOL and relerr(b, b_ref) < OP_TOL
+    assert operr(A, A_ref) < OP_TOL and operr(b, b_ref) < OP_TOL
     truth = 1.0 + 0.1 * rng.randn(ns)
     mod_ref = (proj_ref.reshape(-1, ns) @ truth).reshape(nbl, nf, nt)
-    assert relerr(hy.ptsrc_sampler.apply_proj(fac, truth).cpu().numpy(), mod_ref) < OP_TOL
+    assert operr(hy.ptsrc_sampler.apply_proj(fac, truth).cpu().numpy(), mod_ref) < OP_TOL
 
 
 def test_tiled_sh_projection_matches_untiled_kernel(hy):
@@ -809,4 +810,4 @@ def test_gain_operator_with_autos_and_repeated_pairs(hy):
         X = rng.randn(5, 2 * nant * nmodes)
         Y = op.apply(X)
         for v in range(5):
-            assert relerr(Y[v], gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)) < OP_TOL
+            assert operr(Y[v], gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)) < OP_TOL
