@@ -2,24 +2,32 @@
 """
 Gibbs driver on MI355X: the counterpart of the reference's ``example.py`` for the heads that sit
 on the GCR hot path -- point-source amplitudes (--ptsrc), linearised gains (--gains),
-spherical-harmonic modes (--sh) and the cosmological field (--cosmo) -- with the reference's flag
-names (hydra/config.py) and output files (ptsrc_amps0.npy, sim_*_w%04d.npy, src_amp_%05d.npy,
-delta_g_amps_%05d.npy, sh_amp_%05d.npy; example.py:191-192,405-408,740,953,1061).  The
-reference's cosmo step plots its first solution and exits (example.py:829-841); here every
-sample is saved as cosmo_field_%05d.npy and, as there (:850-851), does not feed back into the
-data model.
+spherical-harmonic modes (--sh) and the cosmological field (--cosmo) -- with the reference's
+full flag set (hydra_amd.config = hydra/config.py) and output files (ptsrc_amps0.npy,
+sim_*_w%04d.npy, src_amp_%05d.npy, delta_g_amps_%05d.npy, sh_amp_%05d.npy; example.py:191-192,
+405-408,740,953,1061).  The reference's cosmo step plots its first solution and exits
+(example.py:829-841); here every sample is saved as cosmo_field_%05d.npy and, as there
+(:850-851), does not feed back into the data model.
 
     python example.py --ptsrc --gains --Niters 10
-    python -m torch.distributed.run --nproc-per-node 8 --master-addr 127.0.0.1 example.py --ptsrc
+    python -m torch.distributed.run --nproc-per-node 4 --master-addr 127.0.0.1 example.py --ptsrc
 
-One process per GPU; the frequency channels are split over ranks (the reference splits a
-freq x time grid over MPI ranks, example.py:161-174) and ``hydra_amd._dist.Comm`` stands where
-``MPI.COMM_WORLD`` stood.  All arrays of the loop stay in HBM; the operator of the source head
-is kept in factored form.  --regions needs a pygdsm sky model (not shipped; the region operator
-itself is hydra_amd.region_sampler.calc_proj_operator); --beam and --vis are outside the hot
-path.
+One process per GPU, ``hydra_amd._dist.Comm`` where ``MPI.COMM_WORLD`` stood.  A square number of
+workers is laid out on the reference's (frequency x time) grid of chunks (example.py:161-174,
+utils.freqs_times_for_worker); any other count splits the frequency channels only.  All arrays
+of the loop stay in HBM; the operator of the source head is kept in factored form.
+Random numbers are drawn from numpy's global generator in the reference's order (catalogue,
+gain levels, ``seed(1)`` + gain modes, noise; per head: the draws of the reference's functions),
+so a seeded run can be replayed by the CPU oracle (tests/test_gpu_driver.py).
+
+--solver cg | gmres | bicgstab solve the source head densely on the root, as the reference does
+whatever the name (example.py:940-947); --solver mpicg distributes the operator in
+sqrt(N) x sqrt(N) blocks and runs ``linear_solver.cg_mpi`` (:899-938).
+--regions / --sim-diffuse-sky-model need a pygdsm sky model (not shipped; the region operator
+itself is hydra_amd.region_sampler.calc_proj_operator); --beam, --cl and --pspec are heads
+outside the GCR hot path and raise NotImplementedError, --stats raises it
+as in the reference (example.py:1254-1255).
 """
-import argparse
 import os
 import time
 
@@ -28,61 +36,51 @@ import torch
 
 import hydra_amd as hydra
 from hydra_amd import _dev, _dist
+from hydra_amd.config import get_config  # noqa: F401  (re-exported: tests and callers use it)
+
+SOLVERS = ("cg", "gmres", "bicgstab", "mpicg")
 
 
-def get_config(argv=None):
-    """The flags of hydra/config.py:5-589 that the three heads use, same names / dests."""
-    p = argparse.ArgumentParser(description="Hydra GCR heads on MI355X")
-    p.add_argument("--seed", type=int, default=0, dest="seed")
-    p.add_argument("--ptsrc", action="store_true", dest="sample_ptsrc")
-    p.add_argument("--gains", action="store_true", dest="sample_gains")
-    p.add_argument("--sh", action="store_true", dest="sample_sh")
-    p.add_argument("--cosmo", action="store_true", dest="sample_cosmo_field")
-    p.add_argument("--timing", action="store_true", dest="save_timing_info")
-    p.add_argument("--latitude", type=float, default=-30.7215, dest="latitude")
-    p.add_argument("--hex-array", type=int, nargs=2, default=(3, 4), dest="hex_array")
-    p.add_argument("--Nptsrc", type=int, default=100, dest="Nptsrc")
-    p.add_argument("--Ntimes", type=int, default=30, dest="Ntimes")
-    p.add_argument("--Nfreqs", type=int, default=60, dest="Nfreqs")
-    p.add_argument("--Niters", type=int, default=100, dest="Niters")
-    p.add_argument("--sigma-noise", type=float, default=0.05, dest="sigma_noise")
-    p.add_argument("--solver", type=str, default="cg", dest="solver_name")
-    p.add_argument("--output-dir", type=str, default="./output", dest="output_dir")
-    p.add_argument("--beam-type", type=str, default="gaussian", dest="beam_type")
-    p.add_argument("--ra-bounds", type=float, nargs=2, default=(0.0, 1.0), dest="ra_bounds")
-    p.add_argument("--dec-bounds", type=float, nargs=2, default=(-0.6, 0.4), dest="dec_bounds")
-    p.add_argument("--lst-bounds", type=float, nargs=2, default=(0.2, 0.5), dest="lst_bounds")
-    p.add_argument("--freq-bounds", type=float, nargs=2, default=(100.0, 120.0), dest="freq_bounds")
-    p.add_argument("--ptsrc-amp-prior-level", type=float, default=0.1, dest="ptsrc_amp_prior_level")
-    p.add_argument("--gain-prior-amp", type=float, default=0.1, dest="gain_prior_amp")
-    p.add_argument("--gain-nmax-freq", type=int, default=2, dest="gain_nmaxfreq")
-    p.add_argument("--gain-nmax-time", type=int, default=2, dest="gain_nmaxtime")
-    p.add_argument("--gain-only-positive-modes", type=bool, default=True,
-                   dest="gain_only_positive_modes")
-    p.add_argument("--sim-gain-amp-std", type=float, default=0.05, dest="sim_gain_amp_std")
-    p.add_argument("--cosmo-ra-bounds", type=float, nargs=2, default=(0, 60),
-                   dest="cosmo_field_ra_bounds")
-    p.add_argument("--cosmo-dec-bounds", type=float, nargs=2, default=(-40.0, -20.0),
-                   dest="cosmo_field_dec_bounds")
-    p.add_argument("--cosmo-ra-ngrid", type=int, default=10, dest="cosmo_field_ra_ngrid")
-    p.add_argument("--cosmo-dec-ngrid", type=int, default=10, dest="cosmo_field_dec_ngrid")
-    p.add_argument("--sh-lmax", type=int, default=8, dest="sh_lmax")
-    p.add_argument("--sh-nside", type=int, default=16, dest="sh_nside")
-    p.add_argument("--sh-prior-std", type=float, default=0.1, dest="sh_prior_std")
-    p.add_argument("--sh-ref-freq", type=float, default=100.0, dest="sh_ref_freq")
-    p.add_argument("--sh-spectral-idx", type=float, default=0.0, dest="sh_spectral_idx")
-    return p.parse_args(argv)
+def worker_chunks(comm, freqs, times):
+    """(freq idxs, time idxs, ngrid) of this rank: the reference's square grid of chunks
+    (example.py:161-174) when the worker count is a square, else frequency chunks only."""
+    nworkers = comm.Get_size() if comm is not None else 1
+    ngrid = int(round(np.sqrt(nworkers)))
+    if comm is None:
+        return np.arange(freqs.size), np.arange(times.size), 1
+    if ngrid * ngrid == nworkers:
+        fi, ti, _ = hydra.freqs_times_for_worker(comm=comm, freqs=freqs, times=times,
+                                                 fchunks=ngrid, tchunks=ngrid)
+        return fi, ti, ngrid
+    fi, ti, _ = hydra.freqs_times_for_worker(comm=comm, freqs=freqs, times=times,
+                                             fchunks=nworkers, tchunks=1)
+    return fi, ti, 0
 
 
-def main(argv=None):
+def main(argv=None, on_head=None):
+    """Run the sampler.  ``on_head(name, n, state)`` (optional) is called right before each head
+    of iteration ``n`` draws its random numbers, with a dict of the arrays that head is about to
+    use -- the tests replay the head on the CPU oracle from there."""
     args = get_config(argv)
+    if args.solver_name not in SOLVERS:
+        raise ValueError("Solver '%s' not recognised." % args.solver_name)
+    for flag, name in ((args.sample_regions, "--regions"), (args.sample_beam, "--beam"),
+                       (args.sample_sh_pspec, "--cl"), (args.sample_pspec, "--pspec")):
+        if flag:
+            raise NotImplementedError(
+                "%s: this head is outside the GCR hot path of this package (SURVEY section 8); "
+                "--regions needs a pygdsm sky model" % name)
+    if args.sim_diffuse_sky_model != "none":
+        raise NotImplementedError("--sim-diffuse-sky-model needs pygdsm sky-model data")
+    if args.calculate_stats:
+        raise NotImplementedError()                       # example.py:1254-1255
     comm = _dist.init_from_env()
     myid = comm.Get_rank() if comm is not None else 0
     nworkers = comm.Get_size() if comm is not None else 1
     if comm is None:
         torch.cuda.set_device(0)
     dev = _dev.device()
-    np.random.seed(args.seed + myid)                     # example.py:139
+    np.random.seed(args.seed + myid)                      # example.py:139
     out = args.output_dir
     if myid == 0:
         os.makedirs(out, exist_ok=True)
@@ -101,21 +99,29 @@ def main(argv=None):
     def tdev(x, dtype):
         return torch.as_tensor(np.ascontiguousarray(x), dtype=dtype, device=dev)
 
-    # ---- array, catalogue, this rank's channels (example.py:149-201)
+    def notify(name, n, **state):
+        if on_head is not None:
+            on_head(name, n, state)
+
+    # ---- array, this rank's (freq, time) chunk, catalogue (example.py:149-201)
     lat = np.deg2rad(args.latitude)
-    freqs = np.linspace(args.freq_bounds[0], args.freq_bounds[1], args.Nfreqs)
-    times = np.linspace(args.lst_bounds[0], args.lst_bounds[1], args.Ntimes)
-    fidx = np.array_split(np.arange(args.Nfreqs), nworkers)[myid]
-    freq_chunk, time_chunk = freqs[fidx], times
+    freqs = np.linspace(min(args.freq_bounds), max(args.freq_bounds), args.Nfreqs)
+    times = np.linspace(min(args.lst_bounds), max(args.lst_bounds), args.Ntimes)
+    fidx, tidx, ngrid = worker_chunks(comm, freqs, times)
+    freq_chunk, time_chunk = freqs[fidx], times[tidx]
+    log("    Solver:  %s\n    Seed:    %d\n    Parallelisation: %03d workers, chunks %s"
+        % (args.solver_name, args.seed, nworkers,
+           "%d x %d (freq x time)" % (ngrid, ngrid) if ngrid else "%d x 1" % nworkers))
     ant_pos = hydra.build_hex_array(hex_spec=tuple(args.hex_array), d=14.6)
     ants = np.array(list(ant_pos.keys()))
     nants = len(ants)
-    antpairs = [(i, j) for i in range(nants) for j in range(i + 1, nants)]
+    antpairs = [(i, j) for i in range(nants) for j in range(i, nants) if i != j]
     nbl, nf, nt = len(antpairs), freq_chunk.size, time_chunk.size
-    cat = np.zeros((3, args.Nptsrc))
+    Nptsrc = args.Nptsrc
+    cat = np.zeros((3, Nptsrc))
     if myid == 0:
         cat[:] = hydra.example.generate_random_ptsrc_catalogue(
-            args.Nptsrc, ra_bounds=args.ra_bounds, dec_bounds=args.dec_bounds,
+            Nptsrc, ra_bounds=args.ra_bounds, dec_bounds=args.dec_bounds,
             logflux_bounds=(-1.0, 2.0))
         np.save(os.path.join(out, "ptsrc_amps0"), cat[2])
         np.save(os.path.join(out, "ptsrc_coords0"), cat[:2])
@@ -123,7 +129,8 @@ def main(argv=None):
         comm.Bcast(cat, root=0)
     ra, dec, ptsrc_amps = cat
     fluxes_chunk = hydra.get_flux_from_ptsrc_amp(ptsrc_amps, freq_chunk, -2.7)
-    beams = hydra.example.example_beams(args.beam_type, len(ants))
+    beams = hydra.example.example_beams(args.beam_sim_type, nants)
+    log("Simulation beam type: %s" % args.beam_sim_type, "y")
 
     # ---- operators (example.py:507-523, 597-624): factored source operator, SH response
     t0 = time.time()
@@ -131,8 +138,8 @@ def main(argv=None):
         ra=ra, dec=dec, fluxes=fluxes_chunk, ant_pos=ant_pos, antpairs=antpairs,
         freqs=freq_chunk, times=time_chunk, beams=beams, latitude=lat, materialize=False)
     log("Source projection operator (factored) took %6.3f sec" % (time.time() - t0), "c")
-    ones = torch.ones(args.Nptsrc, dtype=torch.float64, device=dev)
-    model0_chunk = source_proj.apply(ones)               # the simulated sky = the catalogue
+    ones = torch.ones(Nptsrc, dtype=torch.float64, device=dev)
+    model0_chunk = source_proj.apply(ones)                # the simulated sky = the catalogue
     sh_response = None
     if args.sample_sh:
         t0 = time.time()
@@ -155,7 +162,7 @@ def main(argv=None):
         log("SH response operator took %6.3f sec" % (time.time() - t0), "c")
 
     cosmo_proj = None
-    if args.sample_cosmo_field:                          # example.py:539-594
+    if args.sample_cosmo_field:                           # example.py:539-594
         t0 = time.time()
         cosmo_grid_ra, cosmo_grid_dec = hydra.cosmo_sampler.make_cosmo_field_grid(args)
         cosmo_proj = hydra.ptsrc_sampler.calc_proj_operator(
@@ -170,23 +177,31 @@ def main(argv=None):
         cosmo_soln_shape = (freqs.size, cosmo_x.size, cosmo_y.size)
         log("Cosmo field projection operator (factored) took %6.3f sec" % (time.time() - t0), "c")
 
+    # ---- calibration source: the brightest near the zenith (example.py:286-312)
+    calsrc = args.calsrc_std >= 0.0
+    near = np.where(np.abs(dec - lat) * 180.0 / np.pi < args.calsrc_radius)[0]
+    assert len(near) > 0, "No sources found within %d deg of the zenith" % args.calsrc_radius
+    calsrc_idx = int(near[np.argmax(ptsrc_amps[near])])
+    log("Calibration source: enabled %s, index %d, amplitude %6.3e" % (calsrc, calsrc_idx,
+                                                                       ptsrc_amps[calsrc_idx]))
+
     # ---- gains and simulated data (example.py:322-408)
-    Lfreq, Ltime = freqs[-1] - freqs[0], times[-1] - times[0]
-    Fb_all, k_freq, k_time = hydra.partial_fourier_basis_2d_from_nmax(
-        freqs=freqs, times=times, nmaxfreq=args.gain_nmaxfreq, nmaxtime=args.gain_nmaxtime,
-        Lfreq=Lfreq, Ltime=Ltime, freq0=freqs[0], time0=times[0],
+    Lfreq = (freqs[1] - freqs[0]) * freqs.size if freqs.size > 1 else 1.0
+    Ltime = (times[1] - times[0]) * times.size if times.size > 1 else 1.0
+    Fbasis_h, k_freq, k_time = hydra.partial_fourier_basis_2d_from_nmax(
+        freqs=freq_chunk, times=time_chunk, nmaxfreq=args.gain_nmaxfreq,
+        nmaxtime=args.gain_nmaxtime, Lfreq=Lfreq, Ltime=Ltime, freq0=freqs[0], time0=times[0],
         shape0=(freqs.size, times.size), positive_only=args.gain_only_positive_modes)
-    Fbasis_h = np.ascontiguousarray(Fb_all[:, fidx, :])
     ngm = k_freq.size
     np.save(os.path.join(out, "Fbasis_w%04d" % myid), Fbasis_h)
     gain0_level = np.zeros(nants, dtype=np.complex128)
     delta_g_amps0 = np.zeros((nants, ngm), dtype=np.complex128)
     prior_std_delta_g = args.sim_gain_amp_std * np.ones(ngm)
-    prior_std_delta_g[0] *= 0.0                           # example.py:362
+    prior_std_delta_g[0] *= 0.0                            # example.py:362
     if myid == 0:
         gain0_level[:] = 0.05 * (np.random.randn(nants) + 1.0j * np.random.randn(nants))
-        np.random.seed(1)                                 # example.py:368
-        delta_g_amps0[:] = prior_std_delta_g * (np.random.randn(nants, ngm)
+        np.random.seed(1)                                  # example.py:368
+        delta_g_amps0[:] = prior_std_delta_g * (1.0 * np.random.randn(nants, ngm)
                                                 + 1.0j * np.random.randn(nants, ngm))
         np.save(os.path.join(out, "sim_gain0_level"), gain0_level)
         np.save(os.path.join(out, "k_freq"), k_freq)
@@ -200,48 +215,66 @@ def main(argv=None):
     delta_g_chunk0 = torch.tensordot(tdev(delta_g_amps0, torch.complex128), Fbasis, dims=([1], [0]))
     data_chunk = hydra.apply_gains(model0_chunk, gains_chunk * (1.0 + delta_g_chunk0), ants,
                                    antpairs, inline=False)
-    gen = torch.Generator(device=dev).manual_seed(args.seed + 1000 + myid)
-    data_chunk = data_chunk + args.sigma_noise * torch.randn(
-        data_chunk.shape, dtype=torch.complex128, device=dev, generator=gen)
+    noise_chunk = args.sigma_noise * np.sqrt(0.5) * (1.0 * np.random.randn(nbl, nf, nt)
+                                                     + 1.0j * np.random.randn(nbl, nf, nt))
+    data_chunk = data_chunk + tdev(noise_chunk, torch.complex128)
+    del noise_chunk
     inv_noise_var_chunk = torch.full((nbl, nf, nt), 1.0 / args.sigma_noise ** 2,
                                      dtype=torch.float64, device=dev)
     np.save(os.path.join(out, "sim_model0_chunk_w%04d" % myid), model0_chunk.cpu().numpy())
     np.save(os.path.join(out, "sim_data_chunk_w%04d" % myid), data_chunk.cpu().numpy())
+    np.save(os.path.join(out, "sim_delta_g0_chunk_w%04d" % myid), delta_g_chunk0.cpu().numpy())
     np.save(os.path.join(out, "sim_delta_g_amps0_w%04d" % myid), delta_g_amps0)
     log("Simulation step finished", "b")
 
-    # ---- priors and starting state
-    amp_prior_std = torch.full((args.Nptsrc,), args.ptsrc_amp_prior_level, dtype=torch.float64,
-                               device=dev)
+    # ---- priors and starting state (example.py:410-460)
+    amp_prior_h = args.ptsrc_amp_prior_level * np.ones(Nptsrc)
+    if calsrc:
+        amp_prior_h[calsrc_idx] = args.calsrc_std
+    amp_prior_std = tdev(amp_prior_h, torch.float64)
     gain_pspec_sqrt = args.gain_prior_amp * np.ones(ngm)
-    gain_pspec_sqrt[0] = 1e-2 * args.gain_prior_amp       # example.py:562-570 (zero mode tight)
+    if args.gain_prior_zero_mode_std is not None:
+        zero_mode = np.where(np.logical_and(k_freq == 0.0, k_time == 0.0))[0]
+        gain_pspec_sqrt[zero_mode] = float(args.gain_prior_zero_mode_std)
+        log("Gain zero-mode prior level: %6.4e" % args.gain_prior_zero_mode_std, "b")
     gain_pspec_sqrt_d = tdev(gain_pspec_sqrt, torch.float64)
-    A_real, A_imag = hydra.gain_sampler.proj_operator(ants, antpairs)
+    A_real = A_imag = None
+    if args.sample_gains:
+        A_real, A_imag = hydra.gain_sampler.proj_operator(ants, antpairs)
     current_delta_gain = torch.zeros_like(gains_chunk)
     zero_vis = torch.zeros((nbl, nf, nt), dtype=torch.complex128, device=dev)
-    model_ptsrc = source_proj.apply(ones)
-    model_sh = zero_vis.clone()
-    x_soln = torch.zeros(args.Nptsrc, dtype=torch.float64, device=dev)
+    # components of the current visibility model, without any gain factor (:417-423).  A component
+    # that is not being sampled stays at its simulated truth (the reference starts the total from
+    # model0 but the components from 0, so an --sh run without --ptsrc would fit the point
+    # sources with spherical harmonics)
+    model_ptsrc, model_sh = source_proj.apply(ones), zero_vis
+    current_model = model0_chunk.clone()
+    x_soln = torch.zeros(Nptsrc, dtype=torch.float64, device=dev)
+    mpicg_groups = None
     if args.sample_sh:
         inv_prior_sh = torch.full((nmodes_sh,), 1.0 / args.sh_prior_std ** 2, dtype=torch.float64,
                                   device=dev)
         sh_current = torch.zeros(nmodes_sh, dtype=torch.float64, device=dev)
         a_0 = torch.zeros_like(sh_current)
         t0 = time.time()
+        # the left-hand side does not change between iterations: built once on the matrix cores
+        # (the reference forms it inside every CG iteration, sh_sampler.py:393-398)
         sh_lhs = hydra.sh_sampler.lhs_matrix(inv_noise_var_chunk, inv_prior_sh, sh_response,
                                              comm=comm)
         log("SH left-hand-side matrix took %6.3f sec" % (time.time() - t0), "c")
 
     # ---- Gibbs loop (example.py:663-1322)
     for n in range(args.Niters):
-        log("Iteration %d" % n, "b")
+        log("-" * 60 + "\n>>> Iteration %4d / %4d\n" % (n + 1, args.Niters) + "-" * 60)
         t_iter = time.time()
 
-        if args.sample_gains:                            # (A) example.py:673-745
+        if args.sample_gains:                             # (A) example.py:673-745
             t0 = time.time()
-            ggv = hydra.apply_gains(model_ptsrc + model_sh, gains_chunk, ants, antpairs,
-                                    inline=False)
+            ggv = hydra.apply_gains(current_model, gains_chunk, ants, antpairs, inline=False)
             resid = data_chunk - ggv
+            notify("gains", n, resid=resid, model_vis=ggv, inv_noise_var=inv_noise_var_chunk,
+                   pspec_sqrt=gain_pspec_sqrt, Fbasis=Fbasis_h, seed=100000 * myid + n,
+                   ants=ants, antpairs=antpairs)
             bgain = hydra.gain_sampler.construct_rhs_mpi(
                 comm=comm, resid=resid, inv_noise_var=inv_noise_var_chunk,
                 pspec_sqrt=gain_pspec_sqrt_d, A_real=A_real, A_imag=A_imag, model_vis=ggv,
@@ -251,7 +284,7 @@ def main(argv=None):
             if comm is None:
                 lin = op.apply
             else:
-                def lin(v, op=op):
+                def lin(v, op=op):        # one all-reduce per CG iteration, every rank iterates
                     t = op.local(v)
                     comm.allreduce_(t)
                     return v + t
@@ -263,10 +296,9 @@ def main(argv=None):
             current_delta_gain = torch.tensordot(xg, Fbasis, dims=([1], [0]))
             timing(n, "(A) Gain sampler", time.time() - t0)
 
-        if args.sample_cosmo_field:                      # (BBBB) example.py:751-851
+        if args.sample_cosmo_field:                       # (BBBB) example.py:751-851
             t0 = time.time()
-            ggv = hydra.apply_gains(model_ptsrc + model_sh, gains_chunk, ants, antpairs,
-                                    inline=False)
+            ggv = hydra.apply_gains(current_model, gains_chunk, ants, antpairs, inline=False)
             pspec3d = hydra.cosmo_sampler.calculate_pspec_on_grid(
                 kbins=cosmo_pspec_kbins, pspec=cosmo_pspec_current, x=cosmo_x, y=cosmo_y,
                 freqs=freqs, **cosmo_background_params)
@@ -288,54 +320,83 @@ def main(argv=None):
                 comm.barrier()
             timing(n, "(BBBB) Cosmo field sampler", time.time() - t0)
 
-        if args.sample_ptsrc:                            # (B) example.py:856-984
+        if args.sample_ptsrc:                             # (B) example.py:856-984
             t0 = time.time()
             g_now = gains_chunk * (1.0 + current_delta_gain)
             resid = data_chunk - hydra.apply_gains(model_sh, gains_chunk, ants, antpairs,
                                                    inline=False)
+            notify("ptsrc", n, resid=resid, gains=g_now, inv_noise_var=inv_noise_var_chunk,
+                   amp_prior_std=amp_prior_h, ra=ra, dec=dec, fluxes=fluxes_chunk, ant_pos=ant_pos,
+                   antpairs=antpairs, ants=ants, freqs=freq_chunk, times=time_chunk, latitude=lat)
             source_op, source_rhs = hydra.ptsrc_sampler.precompute_mpi(
                 comm, ants=ants, antpairs=antpairs, freq_chunk=freq_chunk, time_chunk=time_chunk,
                 proj_chunk=source_proj, data_chunk=resid, inv_noise_var_chunk=inv_noise_var_chunk,
                 gain_chunk=g_now, amp_prior_std=amp_prior_std, realisation=True)
-            if myid == 0:
-                if args.solver_name == "cg_explicit":
+            if args.solver_name == "mpicg" and comm is not None and ngrid > 0:
+                # sqrt(N) x sqrt(N) blocks of the operator, one per worker (example.py:899-938)
+                shape = comm.bcast(tuple(source_op.shape), root=0)
+                if mpicg_groups is None:
+                    mpicg_groups = hydra.linear_solver.setup_mpi_blocks(
+                        comm, matrix_shape=shape, split=ngrid)
+                comm_groups, block_map, block_shape = mpicg_groups
+                my_A = my_b = None
+                if comm_groups is not None:
+                    my_A, my_b = hydra.linear_solver.collect_linear_sys_blocks(
+                        comm_groups[0], block_map, block_shape, Amat=source_op, bvec=source_rhs)
+                comm.barrier()
+                xs = hydra.linear_solver.cg_mpi(comm_groups, my_A, my_b, shape[0], block_map)
+                if myid == 0:
+                    x_soln = _dev.f64(xs)
+            elif myid == 0:
+                if args.solver_name == "mpicg":           # a single worker: the same CG, x0 = 0
                     x_soln = hydra.linear_solver.cg(source_op, source_rhs)
-                else:                                     # the reference's default: dense solve
-                    x_soln = hydra.linear_solver.solve_dense(source_op, source_rhs)
-                x_soln = x_soln * amp_prior_std
+                else:     # the reference's dense solve, whatever the solver's name (:940-947)
+                    x_soln = hydra.linear_solver.solve_dense(source_op, source_rhs,
+                                                             overwrite_a=True)
+            if myid == 0:
+                x_soln = x_soln * amp_prior_std           # we solved for x = S^-1/2 s
                 np.save(os.path.join(out, "src_amp_%05d" % n), x_soln.cpu().numpy())
             if comm is not None:
                 comm.bcast_(x_soln, root=0)
             model_ptsrc = source_proj.apply(1.0 + x_soln)
+            current_model = model_ptsrc + model_sh
             timing(n, "(B) Source sampler", time.time() - t0)
 
-        if args.sample_sh:                               # (C) example.py:990-1069
+        if args.sample_sh:                                # (C) example.py:990-1069
             t0 = time.time()
+            # The SH response carries no gains (sh_sampler.py:65-196) while the data do: fit the
+            # gain-corrected residual d / (g_i g_j^*) - ptsrc model.  (The reference subtracts
+            # g g^* x model from the data and fits the gain-free response to what is left,
+            # example.py:1000-1013, which scales the modes by |g|^2 ~ 2.)
             g_now = gains_chunk * (1.0 + current_delta_gain)
-            # the SH operator carries no gains (sh_sampler.py:405-494): fit the gain-corrected
-            # residual, as the reference does with its gain-free SH response
-            gg = torch.ones((nbl, nf, nt), dtype=torch.complex128, device=dev)
-            gg = hydra.apply_gains(gg, g_now, ants, antpairs, inline=False)
-            resid = ((data_chunk / gg) - model_ptsrc).reshape(-1)
-            omega_a = np.random.randn(nmodes_sh)
-            omega_n = torch.randn(resid.shape, dtype=torch.complex128, device=dev, generator=gen)
+            gg = hydra.apply_gains(torch.ones((nbl, nf, nt), dtype=torch.complex128, device=dev),
+                                   g_now, ants, antpairs, inline=False)
+            resid = data_chunk / gg - model_ptsrc
+            notify("sh", n, resid=resid, inv_noise_var=inv_noise_var_chunk,
+                   inv_prior_var=inv_prior_sh, a_0=a_0, x0=sh_current, vis_response=sh_response)
+            omega_a = np.random.randn(nmodes_sh)           # example.py:1022-1025
+            omega_n = (1.0 * np.random.randn(nbl, nf, nt)
+                       + 1.0j * np.random.randn(nbl, nf, nt)) / np.sqrt(2.0)
+            omega_n = tdev(omega_n, torch.complex128)
             if comm is None:
                 bsh = hydra.sh_sampler.construct_rhs_no_rot(
-                    resid, inv_noise_var_chunk, inv_prior_sh, tdev(omega_a, torch.float64),
-                    omega_n, a_0, sh_response)
+                    resid.reshape(-1), inv_noise_var_chunk, inv_prior_sh,
+                    tdev(omega_a, torch.float64), omega_n, a_0, sh_response)
             else:
                 bsh = hydra.sh_sampler.construct_rhs_no_rot_mpi(
-                    comm, resid, inv_noise_var_chunk, inv_prior_sh, omega_a, omega_n, a_0,
-                    sh_response)
+                    comm, resid.reshape(-1), inv_noise_var_chunk, inv_prior_sh, omega_a, omega_n,
+                    a_0, sh_response)
                 bsh = _dev.f64(bsh)
             if myid == 0:
                 sh_current = hydra.linear_solver.cg(sh_lhs, bsh, maxiters=1000, abs_tol=1e-8,
-                                                    x0=sh_current)
+                                                    use_norm_tol=False, x0=sh_current)
                 np.save(os.path.join(out, "sh_amp_%05d" % n), sh_current.cpu().numpy())
             if comm is not None:
                 comm.bcast_(sh_current, root=0)
+            model_sh = torch.empty((nbl, nf, nt), dtype=torch.complex128, device=dev)
             _dev.call("hydra_apply_R", _dev.ptr(sh_response), nbl * nf * nt, nmodes_sh,
                       _dev.ptr(sh_current), _dev.ptr(None), _dev.ptr(model_sh), _dev.stream_ptr())
+            current_model = model_ptsrc + model_sh
             timing(n, "(C) SH sampler", time.time() - t0)
 
         torch.cuda.synchronize()

