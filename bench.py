@@ -59,7 +59,13 @@ SH_CONFIGS = {
     # 128 channels stays resident in one GPU's 288 GB of HBM.
     "c3": ((7, 13), 40, 32, 128, 4),
     "c3s": ((4, 7), 10, 8, 8, 3),
+    # SURVEY 8(d)'s C3: 40 LSTs.  The operator would be 1.1 TB: sh_sampler.StreamedSHOperator keeps
+    # the pixel voltages (128 GB) instead and never forms it (right-hand side through the factored
+    # per-pixel operator, left-hand-side matrix accumulated over LST blocks at set-up)
+    "c3t40": ((7, 13), 40, 32, 128, 40),
+    "c3st": ((4, 7), 10, 8, 8, 5),
 }
+SH_STREAMED = ("c3t40", "c3st")
 GAIN_CONFIGS = {
     # linearised gain head -- name: (hex_spec, Nf, Nt, nmaxfreq, nmaxtime, batch)
     # c4 = BASELINE config 4 (HERA-331 per-antenna perturbations, batched CG matvecs)
@@ -204,6 +210,119 @@ def sh_cpu_baseline(rows, full_rows, nm):
     t_lhs = time.time() - t0
     scale = full_rows / rows
     return {"rhs_s": t_rhs * scale, "lhs_apply_s": t_lhs * scale, "rows": rows, "cores": int(threads)}
+
+
+def main_sh_streamed(args, comm, rank, world, dev):
+    """The SH head with the response operator never in memory (sh_sampler.StreamedSHOperator):
+    per sample the right-hand side b = Y^T Re(P^H (N^-1 d + N^-1/2 w_n)) + prior terms through the
+    factored per-pixel operator (one pass over the pixel voltages, HBM / FP64 bound) and a CG
+    solve with the left-hand-side matrix accumulated over LST blocks at set-up."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import sh_sampler
+    hex_spec, lmax, nside, nf, nt = SH_CONFIGS[args.config]
+    ant_pos = hy.utils.build_hex_array(hex_spec=hex_spec, d=14.6)
+    nant = len(ant_pos)
+    nbl = nant * (nant - 1) // 2
+    freqs = np.linspace(100.0, 120.0, nf)
+    times = np.linspace(0.2, 0.5, nt)
+    fidx = np.array_split(np.arange(nf), world)[rank]
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+
+    def sync():
+        if comm is not None:
+            comm.barrier()
+        torch.cuda.synchronize()
+
+    sync()
+    t0 = time.perf_counter()
+    op = sh_sampler.StreamedSHOperator(freqs[fidx], times, beams, ant_pos, lmax, nside, time_block=1)
+    sync()
+    t_volt = time.perf_counter() - t0
+    m_loc, nm = op.shape
+    m_all = nbl * nf * nt
+    gen = torch.Generator(device=dev).manual_seed(4321 + rank)
+    gen_a = torch.Generator(device=dev).manual_seed(99)
+    prior_std, sigma_noise = 0.1, 0.05
+    inv_prior = torch.full((nm,), 1.0 / prior_std ** 2, dtype=torch.float64, device=dev)
+    inv_noise = torch.full((m_loc,), 1.0 / sigma_noise ** 2, dtype=torch.float64, device=dev)
+    a_true = prior_std * torch.randn(nm, dtype=torch.float64, device=dev, generator=gen_a)
+    data = op.apply(a_true).reshape(-1)
+    data += sigma_noise * torch.randn(m_loc, dtype=torch.complex128, device=dev, generator=gen)
+    a_0 = torch.zeros(nm, dtype=torch.float64, device=dev)
+    sync()
+    t0 = time.perf_counter()
+    A = op.lhs_matrix(inv_noise, inv_prior, comm=comm)
+    sync()
+    t_lhs = time.perf_counter() - t0
+
+    def one_sample(x0):
+        om_a = torch.randn(nm, dtype=torch.float64, device=dev, generator=gen_a)
+        om_n = torch.randn(m_loc, dtype=torch.complex128, device=dev, generator=gen)
+        b = op.construct_rhs(data, inv_noise, inv_prior, om_a, om_n, a_0, comm=comm)
+        x, iters = hy.linear_solver.cg(A, b, maxiters=1000, abs_tol=args.cg_tol, x0=x0,
+                                       return_iters=True)      # replicated A: every rank solves
+        return b, x, iters
+
+    x = torch.zeros(nm, dtype=torch.float64, device=dev)
+    for _ in range(args.warmup):
+        b, x, iters = one_sample(x)
+    sync()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        b, x, iters = one_sample(x)
+    sync()
+    elapsed = time.perf_counter() - t0
+    t_all = torch.tensor([elapsed], dtype=torch.float64, device=dev)
+    if comm is not None:
+        comm.allreduce_(t_all, op="max")
+    elapsed = float(t_all.item())
+    # the adjoint pass alone, HIP events on the launch stream
+    z = torch.randn(m_loc, dtype=torch.complex128, device=dev, generator=gen)
+    op.adjoint(z)
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(2):
+        op.adjoint(z)
+    e1.record()
+    torch.cuda.synchronize()
+    adj_ms = e0.elapsed_time(e1) / 2
+    if rank != 0:
+        return
+    resid = float((torch.linalg.norm(A @ x - b) / torch.linalg.norm(b)).item())
+    vbytes = 16.0 * op.V.numel() + 16.0 * m_loc            # V once + z
+    flops = 8.0 * m_loc * op.npix
+    out = {
+        "metric": "GCR samples/sec (SH head, whole job)",
+        "value": args.steps / elapsed, "unit": "samples/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / args.steps,
+        "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
+        "data": "synthetic",
+        "config": {
+            "workload": (f"BASELINE config 3 at SURVEY 8(d)'s size ({args.config}): SH diffuse GCR, "
+                         f"hex{hex_spec} = {nant} antennas / {nbl} baselines, lmax {lmax} ({nm} real "
+                         f"modes), nside {nside}, {nf} freqs x {nt} times, complex128; the response "
+                         f"operator ({16e-9 * m_all * nm:.0f} GB) is never formed: pixel voltages "
+                         f"resident ({16e-9 * op.V.numel():.1f} GB per GPU), left-hand-side matrix "
+                         f"accumulated over LST blocks at set-up"),
+            "rows_M": m_all, "solver": "cg", "cg_abs_tol": args.cg_tol, "cg_iters_last": int(iters),
+            "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
+        },
+        "setup_voltages_s": t_volt, "setup_lhs_matrix_s": t_lhs,
+        "setup_lhs_tflops": (2.0 * m_loc * op.npix * nm + 2.0 * m_loc * nm * (nm + 1)) / t_lhs / 1e12,
+        "sample_rel_residual": resid,
+        "roofline": {
+            "bound": "hbm", "achieved": vbytes / (adj_ms * 1e-3) / 1e9, "peak": 8000.0, "unit": "GB/s",
+            "frac": vbytes / (adj_ms * 1e-3) / 1e9 / 8000.0, "traffic": None,
+            "kernel": "adjoint_V_kernel (R^H z through the factored per-pixel operator) + Y^T GEMV",
+            "ms_per_launch": adj_ms, "bytes_per_launch": vbytes,
+            "fp64_tflops": flops / (adj_ms * 1e-3) / 1e12,
+            "note": ("8 M Npix flops on the vector units against 16 Nft Nant Npix bytes of voltages: "
+                     "at 127 antennas the pass is FP64-VALU-bound, not HBM-bound"),
+        },
+        "cpu_baseline": None,
+    }
+    print(json.dumps(out))
 
 
 def main_sh(args, comm, rank, world, dev):
@@ -829,6 +948,8 @@ def main():
     if comm is None:
         torch.cuda.set_device(0)
     dev = _dev.device()
+    if args.config in SH_STREAMED:
+        return main_sh_streamed(args, comm, rank, world, dev)
     if args.config in SH_CONFIGS:
         return main_sh(args, comm, rank, world, dev)
     if args.config in GAIN_CONFIGS:

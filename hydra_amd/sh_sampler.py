@@ -244,6 +244,124 @@ class LhsOperator:
         return _dev.like(a_cr, tot + self.ip * a)
 
 
+class StreamedSHOperator:
+    """The SH response operator of ``vis_proj_operator_no_rot`` WITHOUT its (Nvis, Nm) matrix in
+    memory -- for time axes whose operator does not fit HBM (HERA-127, lmax 40, 128 channels:
+    27.5 GB per LST; 40 LSTs = 1.1 TB).  R = diag(spec) P Y factors into the per-pixel operator
+    P[(b,f,t),p] = conj(V_i,p) V_j,p (pixel voltages V, vis_simulator.py:657-673) and the real mode
+    maps Y (Npix, Nm) (:702-730), so
+
+        R^T z        = Y^T Re(P^H (spec z))        one pass over V (``FactoredProj.adjoint``) + a GEMV
+        R a          = spec P (Y a)                a GEMV + one pass over V (``FactoredProj.apply``)
+        Re(R^H W R)  = sum over LST blocks of the Gram of the block's operator, regenerated on
+                       the matrix cores block by block (``hydra_sh_project_tiled`` + ``hydra_gram``)
+
+    -- nothing of size (Nvis, Nm) persists.  ``time_block`` LSTs are projected at a time.  The
+    right-hand side and left-hand side equal ``construct_rhs_no_rot`` / ``lhs_matrix`` on the
+    materialised operator up to summation order (sh_sampler.py:370-402)."""
+
+    def __init__(self, freqs, lsts, beams, ant_pos, lmax, nside,
+                 latitude=-0.5361913261514378, ref_freq=100.0, spectral_idx=0.0, time_block=2):
+        from .ptsrc_sampler import FactoredProj
+        self.freqs = np.asarray(freqs, dtype=np.float64)
+        self.lsts = np.atleast_1d(np.asarray(lsts, dtype=np.float64))
+        self.ell, self.m = _vs.getlm(lmax)
+        names = list(ant_pos.keys())
+        cross, _ = _pairs(names, False, False)
+        self.bl_i = np.array([names.index(p[0]) for p in cross], dtype=np.int32)
+        self.bl_j = np.array([names.index(p[1]) for p in cross], dtype=np.int32)
+        self.nbl, self.nf, self.nt = len(cross), self.freqs.size, self.lsts.size
+        self.ymap = _vs.sh_mode_maps(lmax, nside, 1.0, packed=True)          # (Npix, Nm)
+        self.ymap_t = self.ymap.T.contiguous()                               # (Nm, Npix)
+        self.npix, self.nm = self.ymap.shape
+        # the spectral factor (f / ref)^beta of sh_sampler.py:164-168 rides on the pixel fluxes:
+        # V carries its square root, conj(V_i) V_j the factor itself
+        self.spec = (self.freqs / ref_freq) ** spectral_idx
+        self.time_block = max(1, int(time_block))
+        self._args = (nside, ant_pos, beams, latitude)
+        # pixel voltages of all LSTs stay resident: (Nf, Nt, Nant, Npix) c128, (Nant-1)/2 x Nm/Npix
+        # times smaller than the operator
+        self.V = _vs.sh_voltages(nside, ant_pos, self.freqs * 1e6, self.lsts, beams, latitude,
+                                 flux_f=self.spec)
+        self.fac = FactoredProj(self.V, self.bl_i, self.bl_j)
+        self.shape = (self.nbl * self.nf * self.nt, self.nm)
+
+    def _block_response(self, t0, t1):
+        """The operator of LSTs [t0, t1) as a matrix, rows in (b, f, t) order of that block."""
+        nside, ant_pos, beams, latitude = self._args
+        Vb = _vs.sh_voltages(nside, ant_pos, self.freqs * 1e6, self.lsts[t0:t1], beams, latitude,
+                             flux_f=self.spec)
+        out = _vs.sh_project(Vb, self.bl_i, self.bl_j, self.ymap)
+        return out.reshape(self.nbl * self.nf * (t1 - t0), self.nm)
+
+    def lhs_matrix(self, inv_noise_var, inv_prior_var, comm=None):
+        """A = Re(R^H N^-1 R) + diag(S^-1), accumulated over LST blocks (``lhs_matrix`` of the
+        module on an operator that is never whole)."""
+        w = _dev.f64(inv_noise_var).reshape(self.nbl, self.nf, self.nt)
+        ip = _dev.f64(inv_prior_var)
+        A = torch.zeros((self.nm, self.nm), dtype=torch.float64, device=w.device)
+        G = _dev.empty((self.nm, self.nm), torch.float64)
+        for t0 in range(0, self.nt, self.time_block):
+            t1 = min(self.nt, t0 + self.time_block)
+            R = self._block_response(t0, t1)
+            wb = w[:, :, t0:t1].contiguous().reshape(-1)
+            rows = torch.complex(torch.sqrt(wb), torch.zeros_like(wb))
+            ws = _dev.workspace(_dev._lib.query("hydra_gram_workspace_bytes", R.shape[0], self.nm))
+            _dev.call("hydra_gram", _dev.ptr(R), _dev.ptr(rows), R.shape[0], self.nm,
+                      _dev.ptr(None), _dev.ptr(None), _dev.ptr(G), _dev.ptr(ws), ws.numel(),
+                      _dev.stream_ptr())
+            A += G
+            del R, ws
+        if comm is not None:
+            comm.allreduce_sym_(A)
+        _dev.call("hydra_prior_epilogue", _dev.ptr(A), self.nm, _dev.ptr(None), _dev.ptr(ip),
+                  _dev.stream_ptr())
+        A.hydra_symmetric = True
+        return A
+
+    def _rows(self, x):
+        return _dev.c128(x).reshape(self.nbl, self.nf, self.nt)
+
+    def adjoint(self, z):
+        """Re(R^H z) (Nm,) for z like the visibilities."""
+        t_pix = self.fac.adjoint(self._rows(z).contiguous())
+        out = _dev.empty((self.nm,), torch.float64)
+        _dev.call("hydra_gemv_rows", _dev.ptr(self.ymap_t), self.nm, self.npix, _dev.ptr(t_pix),
+                  _dev.ptr(out), 0, _dev.stream_ptr())
+        return out
+
+    def apply(self, a):
+        """R a (Nbl, Nf, Nt) complex -- the model update of the driver (example.py:1065)."""
+        sky = _dev.empty((self.npix,), torch.float64)
+        ad = _dev.f64(a)
+        _dev.call("hydra_gemv_rows", _dev.ptr(self.ymap), self.npix, self.nm, _dev.ptr(ad),
+                  _dev.ptr(sky), 0, _dev.stream_ptr())
+        return self.fac.apply(sky)
+
+    def construct_rhs(self, data, inv_noise_var, inv_prior_var, omega_0, omega_1, a_0, comm=None):
+        """``construct_rhs_no_rot`` (sh_sampler.py:370-386); with ``comm`` the data terms of the
+        ranks' chunks are all-reduced and every rank returns the full vector."""
+        d, w, om = self._rows(data), _dev.f64(inv_noise_var).reshape(-1), self._rows(omega_1)
+        m = d.numel()
+        z = _dev.empty((m,), torch.complex128)
+        _dev.call("hydra_rhs_rows", _dev.ptr(d), _dev.ptr(None), _dev.ptr(w), _dev.ptr(om),
+                  _dev.ptr(None), m, _dev.ptr(z), _dev.stream_ptr())
+        term = self.adjoint(z)
+        if comm is not None:
+            comm.allreduce_(term)
+        ip = _dev.f64(inv_prior_var)
+        return term + (ip * _dev.f64(a_0) + torch.sqrt(ip) * _dev.f64(omega_0))
+
+    def apply_lhs(self, a_cr, inv_noise_var, inv_prior_var):
+        """(R^T N^-1 R + S^-1) a, matrix-free (``apply_lhs_no_rot``, sh_sampler.py:389-402)."""
+        a = _dev.f64(a_cr)
+        y = self.apply(a)
+        w = _dev.f64(inv_noise_var).reshape(-1)
+        _dev.call("hydra_scale_rows", _dev.ptr(y), _dev.ptr(w), y.numel(), _dev.ptr(y),
+                  _dev.stream_ptr())
+        return self.adjoint(y) + _dev.f64(inv_prior_var) * a
+
+
 def lhs_matrix(inv_noise_var, inv_prior_var, vis_response, comm=None):
     """The SH left-hand-side operator as an explicit matrix
     A = Re(R^H N^-1 R) + diag(S^-1), built once on the FP64 matrix cores (csrc/gram.hip), so

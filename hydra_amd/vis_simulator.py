@@ -291,7 +291,7 @@ def sh_mode_maps(lmax, nside, amplitude=1.0, packed=False):
     return ymap
 
 
-def sh_voltages(nside, ants, freqs, lsts, beams, latitude=DEFAULT_LATITUDE):
+def sh_voltages(nside, ants, freqs, lsts, beams, latitude=DEFAULT_LATITUDE, flux_f=None):
     """Voltages of the HEALPix pixels treated as unit-flux sources, with the reference's
     coordinate convention dec = theta - pi/2, ra = phi (vis_simulator.py:657-664).  The tensor
     carries ``hydra_pixidx`` / ``hydra_npix_t``: per time the indices of the pixels above the
@@ -300,6 +300,8 @@ def sh_voltages(nside, ants, freqs, lsts, beams, latitude=DEFAULT_LATITUDE):
     dec = theta - 0.5 * np.pi
     freqs = np.atleast_1d(np.asarray(freqs, dtype=np.float64))
     fluxes = torch.ones((theta.numel(), freqs.size), dtype=torch.float64, device=theta.device)
+    if flux_f is not None:      # a per-channel flux of every pixel: scales conj(V_i) V_j by flux_f / 1
+        fluxes = fluxes * _dev.f64(flux_f)[None, :]
     _beams.check_beams(beams)
     assert len(ants) == len(beams), (
         "The `beams` list must have as many entries as the ``ants`` dict.")

@@ -355,3 +355,83 @@ def test_c5_shaped_sample_meets_the_residual_gate_with_the_dense_solve():
     x_cg, iters = linear_solver.cg(A, b, maxiters=1000, abs_tol=1e-8, return_iters=True)
     res_cg = float(torch.linalg.norm(A @ x_cg - b) / torch.linalg.norm(b))
     assert res < res_cg or iters < 1000
+
+
+# ---------------------------------------------------------------------------- c3, streamed
+
+def test_streamed_sh_operator_matches_materialised_operator_and_oracle():
+    """sh_sampler.StreamedSHOperator (no (Nvis, Nm) matrix in memory) against the materialised
+    operator and the oracle on a small array: right-hand side, operator application, model
+    update and the block-accumulated left-hand-side matrix; spectral index != 0; LST count not a
+    multiple of the block."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import sh_sampler
+    from oracle import beams as obeams, gcr_sh, helpers
+    ant_pos = helpers.build_hex_array((2, 3))
+    nant = len(ant_pos)
+    freqs, lsts = np.linspace(100.0, 120.0, 4), np.linspace(0.2, 0.5, 5)
+    lmax, nside = 6, 8
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bo = [obeams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    R_ref, _, ell, m = gcr_sh.vis_proj_operator_no_rot(freqs, lsts, bo, ant_pos, lmax, nside,
+                                                       latitude=LAT, ref_freq=110.0, spectral_idx=-2.5)
+    op = sh_sampler.StreamedSHOperator(freqs, lsts, bh, ant_pos, lmax, nside, latitude=LAT,
+                                       ref_freq=110.0, spectral_idx=-2.5, time_block=2)
+    mrows, nm = R_ref.shape
+    assert op.shape == (mrows, nm) and mrows == nant * (nant - 1) // 2 * 4 * 5
+    rng = np.random.RandomState(4)
+    w = 300.0 + 200.0 * rng.rand(mrows)
+    ip = 50.0 + 50.0 * rng.rand(nm)
+    d = rng.randn(mrows) + 1j * rng.randn(mrows)
+    om1 = (rng.randn(mrows) + 1j * rng.randn(mrows)) / np.sqrt(2)
+    om0, a0, a = rng.randn(nm), 0.1 * rng.randn(nm), rng.randn(nm)
+    b_ref = gcr_sh.construct_rhs_no_rot(d, w, ip, om0, om1, a0, R_ref)
+    b = op.construct_rhs(d, w, ip, om0, om1, a0).cpu().numpy()
+    assert relerr(b, b_ref) < 1e-10 and elem_err(b, b_ref) <= 1.0
+    y_ref = (R_ref @ a).reshape(op.nbl, op.nf, op.nt)
+    y = op.apply(a).cpu().numpy()
+    assert relerr(y, y_ref) < 1e-10
+    lhs_ref = gcr_sh.apply_lhs_no_rot(a, w, ip, R_ref)
+    lhs = op.apply_lhs(a, w, ip).cpu().numpy()
+    assert relerr(lhs, lhs_ref) < 1e-10
+    A = op.lhs_matrix(w, ip).cpu().numpy()
+    A_ref = R_ref.real.T @ (w[:, None] * R_ref.real) + R_ref.imag.T @ (w[:, None] * R_ref.imag) \
+        + np.diag(ip)
+    assert relerr(A, A_ref) < 1e-10 and np.array_equal(A, A.T)
+    # and the materialised HIP operator agrees with both
+    R, _, _ = sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside, latitude=LAT,
+                                                  ref_freq=110.0, spectral_idx=-2.5, cross_only=True)
+    assert relerr(R, R_ref) < 1e-10
+
+
+def test_c3_streamed_operator_full_array_equals_resident_operator(c3):
+    """HERA-127, lmax 40, nside 32, 128 channels x 2 LSTs: the streamed operator's right-hand
+    side, application and left-hand-side matrix equal those of the resident (materialised)
+    operator of the fixture."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import _dev, sh_sampler
+    R = c3["R"]
+    mrows, nm = R.shape
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in c3["ant_pos"]]
+    op = sh_sampler.StreamedSHOperator(c3["freqs"], c3["times"], beams, c3["ant_pos"], c3["lmax"],
+                                       c3["nside"], latitude=sh_sampler.vis_proj_operator_no_rot.__defaults__[0],
+                                       time_block=1)
+    assert op.shape == (mrows, nm)
+    gen = torch.Generator(device=R.device).manual_seed(21)
+    a = torch.randn(nm, dtype=torch.float64, device=R.device, generator=gen)
+    z = torch.randn(mrows, dtype=torch.complex128, device=R.device, generator=gen)
+    w = 300.0 + 200.0 * torch.rand(mrows, dtype=torch.float64, device=R.device, generator=gen)
+    ip = torch.full((nm,), 100.0, dtype=torch.float64, device=R.device)
+    want = sh_sampler._adjoint(R, z)
+    got = op.adjoint(z)
+    assert float((got - want).abs().max() / want.abs().max()) < 1e-11
+    Ra = _dev.empty((mrows,), torch.complex128)
+    _dev.call("hydra_apply_R", _dev.ptr(R), mrows, nm, _dev.ptr(a), _dev.ptr(None), _dev.ptr(Ra),
+              _dev.stream_ptr())
+    got = op.apply(a).reshape(-1)
+    assert float((got - Ra).abs().max() / Ra.abs().max()) < 1e-11
+    A_res = sh_sampler.lhs_matrix(w, ip, R)
+    A_str = op.lhs_matrix(w, ip)
+    assert float((A_str - A_res).abs().max() / A_res.abs().max()) < 1e-11
