@@ -615,6 +615,193 @@ static void adjoint_plan(long long m, int ns, int* nchunk, long long* rows_per_c
 // test hook: 0 forces the pair-loop kernels (hydra_debug_adjoint_mfma)
 static int g_adjoint_mfma = 1;
 
+// ---- R^H z in antenna space for arrays of MORE than 64 antennas ------------------------------------
+// The same identity as adjoint_V_mfma_kernel -- W = Zc V per (f,t), Zc[i][j] = conj(z_ij) for the
+// listed pairs i <= j, then out[s] += Re sum_i V_i,s conj(W_i,s) -- but neither Zc (127 antennas:
+// 258 KB) nor a lane's voltages (Nant / 4 registers pairs) fit on chip whole:
+//   * the voltages of a 32-source tile, all antennas, are staged in LDS by LDS-DMA, double buffered
+//     over (f,t) (rows of 512 B: the four antenna rows x 16 sources of a B-operand read fall on
+//     disjoint banks);
+//   * Zc is laid out beforehand in MFMA-fragment order (adjbig_frag_kernel): the A operand of
+//     row block rb and k-step kk is 64 consecutive entries, one per lane, read straight from
+//     global memory / L2 (every source tile of an (f,t) reads the same fragments);
+//   * only k-steps on and right of the block diagonal exist (Zc is upper triangular); the four
+//     waves of a workgroup share the source tile and take row blocks in pairs (k, nr-1-k), which
+//     have the same number of k-steps together.
+// Three real products per complex one: P1 = Zr Vr, P2 = Zi Vi, P3 = (Zr + Zi)(Vr + Vi).
+// Work: 6 Nant_p^2/2 Ns flops per (f,t) executed (8 M Ns in the baseline-form count); V is read
+// from HBM once.  The pair loop on the vector units it replaces is LDS-bound at ~5 TFLOP/s.
+constexpr int AB_SRC = 32;            // sources per workgroup tile (two 16-wide column blocks)
+
+__host__ __device__ inline int adjbig_prefix(int rb, int nk) { return rb * nk - 2 * rb * (rb - 1); }
+
+// tab[i * nap + j] = baseline index of the pair (i, j), -1 if absent (nap = 16 nr)
+__global__ void __launch_bounds__(256)
+adjbig_table_kernel(const int32_t* __restrict__ bl_i, const int32_t* __restrict__ bl_j, int nbl,
+                    int nap, int32_t* __restrict__ tab) {
+  for (int b = blockIdx.x * blockDim.x + threadIdx.x; b < nbl; b += gridDim.x * blockDim.x)
+    tab[bl_i[b] * nap + bl_j[b]] = b;
+}
+
+// Fragments of Zc for every (f,t): zri[(ft * nsteps + step) * 64 + lane] = conj(z[b]) with
+// i = 16 rb + (lane & 15), j = 4 kk + (lane >> 4), step = prefix(rb) + kk - 4 rb; zs = re + im.
+__global__ void __launch_bounds__(256)
+adjbig_frag_kernel(const f64x2* __restrict__ zt, const int32_t* __restrict__ tab, int nbl, int nft,
+                   int nr, int nsteps, f64x2* __restrict__ zri, double* __restrict__ zs) {
+  const int nk = 4 * nr, nap = 16 * nr;
+  const int lane = threadIdx.x & 63;
+  const int step = blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (step >= nsteps) return;
+  int rb = 0;
+  while (rb + 1 < nr && adjbig_prefix(rb + 1, nk) <= step) ++rb;
+  const int kk = 4 * rb + step - adjbig_prefix(rb, nk);
+  const int i = 16 * rb + (lane & 15), j = 4 * kk + (lane >> 4);
+  const int b = (j >= i) ? tab[i * nap + j] : -1;
+  for (int ft = blockIdx.y; ft < nft; ft += gridDim.y) {
+    f64x2 v = {0.0, 0.0};
+    if (b >= 0) {
+      f64x2 zv = zt[(size_t)ft * nbl + b];
+      v = f64x2{zv.x, -zv.y};
+    }
+    size_t o = ((size_t)ft * nsteps + step) * 64 + lane;
+    zri[o] = v;
+    zs[o] = v.x + v.y;
+  }
+}
+
+// Five waves: waves 0-3 multiply, wave 4 only stages the next voltage tile.  The split is what
+// lets the multiplying waves pipeline their operand loads: an LDS-DMA operation counts on vmcnt and,
+// being a FLAT-encoded instruction that touches LDS, makes the compiler drain vmcnt AND lgkmcnt to
+// zero at the next dependent use in the wave that issued it -- one full memory latency per group of
+// MFMAs.  In a wave of its own it delays nobody.
+constexpr int AB_THREADS = 320;
+
+__global__ void __launch_bounds__(AB_THREADS)
+adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int nr,
+                     const f64x2* __restrict__ zri, const double* __restrict__ zs, int ft_per_split,
+                     double* __restrict__ partial) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nk = 4 * nr, nap = 16 * nr, nsteps = adjbig_prefix(nr, nk);
+  f64x2* s_v = reinterpret_cast<f64x2*>(smem);                 // [2][nap][AB_SRC]
+  double* s_red = reinterpret_cast<double*>(smem);             // [16][AB_SRC], after the loop
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);   // scalar: the loops branch, not mask
+  const int kr = lane >> 4, lc = lane & 15;
+  const int s0 = blockIdx.x * AB_SRC;
+  const int ft0 = blockIdx.y * ft_per_split, ft1 = min(ft0 + ft_per_split, nft);
+
+  // LDS-DMA of one (f,t) tile: a piece = 2 antenna rows x 32 sources = 1 KiB.  Rows beyond Nant
+  // repeat row Nant-1 (they only meet zero entries of Zc), sources beyond Ns repeat source Ns-1
+  // (their sums are not stored).
+  const unsigned lane_off = (unsigned)min(s0 + (lane & 31), ns - 1) * 16u;
+  auto stage = [&](int ft, int buf) {
+    const char* vft = reinterpret_cast<const char*>(V + (size_t)ft * nant * ns);
+    for (int q = 0; q < nap / 2; ++q) {
+      const int row = min(2 * q + (lane >> 5), nant - 1);
+      const char* src = vft + (size_t)row * ns * 16 + lane_off;
+      f64x2* dst = s_v + ((size_t)buf * nap + 2 * q) * AB_SRC;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    }
+  };
+
+  // operands of one group = four k-steps = one 16-antenna column block of Zc
+  struct Group {
+    f64x2 z[4];
+    double s[4];
+    f64x2 v0[4], v1[4];
+  };
+
+  double acc[2] = {0.0, 0.0};
+  if (wave == 4 && ft0 < ft1) stage(ft0, 0);
+  for (int ft = ft0; ft < ft1; ++ft) {
+    const int buf = (ft - ft0) & 1;
+    if (wave == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                      // tile ft has landed; the other buffer is free
+    if (wave == 4) {
+      if (ft + 1 < ft1) stage(ft + 1, buf ^ 1);
+      continue;
+    }
+    const f64x2* vb = s_v + (size_t)buf * nap * AB_SRC;
+    const f64x2* zr_ft = zri + (size_t)ft * nsteps * 64 + lane;
+    const double* zs_ft = zs + (size_t)ft * nsteps * 64 + lane;
+    auto row_block = [&](int rb) {
+      f64x4 p1[2], p2[2], p3[2];
+#pragma unroll
+      for (int c = 0; c < 2; ++c) {
+        p1[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        p2[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+        p3[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+      }
+      const int ng = nr - rb;                      // groups of this row block
+      const f64x2* zp = zr_ft + (size_t)adjbig_prefix(rb, nk) * 64;
+      const double* zq = zs_ft + (size_t)adjbig_prefix(rb, nk) * 64;
+      const f64x2* vp = vb + (size_t)(16 * rb + kr) * AB_SRC + lc;
+      auto load = [&](Group& o, int g) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          o.z[u] = zp[(size_t)(4 * g + u) * 64];
+          o.s[u] = zq[(size_t)(4 * g + u) * 64];
+          o.v0[u] = vp[(size_t)(4 * g + u) * 4 * AB_SRC];
+          o.v1[u] = vp[(size_t)(4 * g + u) * 4 * AB_SRC + 16];
+        }
+        __builtin_amdgcn_sched_barrier(0);     // the loads stay ahead of the other set's MFMAs
+      };
+      auto mma = [&](const Group& o) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double s0v = o.v0[u].x + o.v0[u].y, s1v = o.v1[u].x + o.v1[u].y;
+          p1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].x, o.v0[u].x, p1[0], 0, 0, 0);
+          p1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].x, o.v1[u].x, p1[1], 0, 0, 0);
+          p2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].y, o.v0[u].y, p2[0], 0, 0, 0);
+          p2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].y, o.v1[u].y, p2[1], 0, 0, 0);
+          p3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.s[u], s0v, p3[0], 0, 0, 0);
+          p3[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.s[u], s1v, p3[1], 0, 0, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // two operand sets in turn: group g + 1 loads while group g multiplies (no register moves)
+      Group ga, gb;
+      load(ga, 0);
+      // (no branch inside the loop body: a conditional use lets the compiler sink the loads next
+      // to it; for an even group count the last load of ga is unused)
+      for (int g = 0; g + 1 < ng; g += 2) {
+        load(gb, g + 1);
+        mma(ga);
+        load(ga, min(g + 2, ng - 1));
+        mma(gb);
+      }
+      if (ng & 1) mma(ga);
+      // Re(V_i conj(W_i)) for the rows this lane holds: antenna 16 rb + kr + 4 g
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f64x2 vv = vb[(size_t)(16 * rb + kr + 4 * g) * AB_SRC + 16 * c + lc];
+          const double wre = p1[c][g] - p2[c][g];
+          const double wim = p3[c][g] - p1[c][g] - p2[c][g];
+          acc[c] += vv.x * wre + vv.y * wim;
+        }
+    };
+    for (int k = wave; 2 * k < nr; k += 4) {
+      row_block(k);
+      if (nr - 1 - k != k) row_block(nr - 1 - k);
+    }
+  }
+  __syncthreads();                         // everyone is done with the voltage tiles
+  if (wave < 4) {
+    s_red[(wave * 4 + kr) * AB_SRC + lc] = acc[0];
+    s_red[(wave * 4 + kr) * AB_SRC + 16 + lc] = acc[1];
+  }
+  __syncthreads();
+  if (tid < AB_SRC && s0 + tid < ns) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s_red[q * AB_SRC + tid];
+    partial[(size_t)blockIdx.y * ns + s0 + tid] = t;
+  }
+}
+
 static void adjoint_V_plan(int nft, int ns, int* nsplit, int* per) {
   int chunks = (ns + 63) / 64;   // (sized for the 64-wide kernel; the 16-wide one just has more chunks)
   int want = std::max(1, std::min(nft, 2048 / chunks));
@@ -783,6 +970,75 @@ int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const i
     HYDRA_CHECK_ARG(seg_host[r] <= seg_host[r + 1], "hydra_vis_regions: segment %d is reversed", r);
   return launch_apply_V("hydra_vis_regions", V, nf, nt, nant, ns, bl_i, bl_j, nbl, nullptr, nullptr,
                         out, seg, nreg, stream);
+}
+
+static void adjbig_plan(int nft, int ns, int* nsplit, int* per) {
+  int tiles = (ns + AB_SRC - 1) / AB_SRC;
+  int want = std::max(1, std::min(nft, 2048 / std::max(tiles, 1)));
+  *per = (nft + want - 1) / want;
+  *nsplit = (nft + *per - 1) / *per;
+}
+
+size_t hydra_adjoint_V_antspace_workspace_bytes(int nf, int nt, int nant, int nbl, int ns) {
+  if (nf <= 0 || nt <= 0 || nant <= 0 || nbl <= 0 || ns <= 0) return 0;
+  int nft = nf * nt, nsplit, per;
+  adjbig_plan(nft, ns, &nsplit, &per);
+  const int nr = (nant + 15) / 16, nk = 4 * nr, nap = 16 * nr;
+  const size_t nsteps = (size_t)adjbig_prefix(nr, nk);
+  return align_up((size_t)nsplit * ns * sizeof(double), 256) +          // partial sums
+         align_up((size_t)nft * nbl * 16, 256) +                        // z transposed
+         align_up((size_t)nap * nap * sizeof(int32_t), 256) +           // pair table
+         align_up((size_t)nft * nsteps * 64 * 16, 256) +                // Zc fragments (re, im)
+         align_up((size_t)nft * nsteps * 64 * 8, 256);                  // Zc fragments (re + im)
+}
+
+int hydra_adjoint_V_antspace(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                             const int32_t* bl_j, int nbl, const double* z, const double* scale,
+                             const double* add, double* out, void* workspace,
+                             size_t workspace_bytes, void* stream) {
+  HYDRA_CHECK_ARG(V && bl_i && bl_j && z && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
+                  "hydra_adjoint_V_antspace: bad arguments");
+  const int nr = (nant + 15) / 16, nk = 4 * nr, nap = 16 * nr;
+  const size_t lds = std::max<size_t>((size_t)2 * nap * AB_SRC * 16, (size_t)16 * AB_SRC * 8);
+  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_adjoint_V_antspace: nant=%d exceeds the LDS tile (160)",
+                  nant);
+  HYDRA_CHECK_ARG((size_t)nant * ns * 16 < ((size_t)1 << 32),
+                  "hydra_adjoint_V_antspace: one (f,t) slice of V must be below 4 GiB");
+  size_t need = hydra_adjoint_V_antspace_workspace_bytes(nf, nt, nant, nbl, ns);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_adjoint_V_antspace: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  int nft = nf * nt, nsplit, per;
+  adjbig_plan(nft, ns, &nsplit, &per);
+  HYDRA_CHECK_ARG(nsplit <= 65535, "hydra_adjoint_V_antspace: too many splits");
+  const int nsteps = adjbig_prefix(nr, nk);
+  unsigned char* w = static_cast<unsigned char*>(workspace);
+  double* partial = reinterpret_cast<double*>(w);
+  w += align_up((size_t)nsplit * ns * sizeof(double), 256);
+  f64x2* zt = reinterpret_cast<f64x2*>(w);
+  w += align_up((size_t)nft * nbl * 16, 256);
+  int32_t* tab = reinterpret_cast<int32_t*>(w);
+  w += align_up((size_t)nap * nap * sizeof(int32_t), 256);
+  f64x2* zri = reinterpret_cast<f64x2*>(w);
+  w += align_up((size_t)nft * nsteps * 64 * 16, 256);
+  double* zs = reinterpret_cast<double*>(w);
+  hipStream_t st = as_stream(stream);
+  hipError_t e = hipMemsetAsync(tab, 0xff, (size_t)nap * nap * sizeof(int32_t), st);   // -1
+  if (e != hipSuccess)
+    return fail(HYDRA_ERR_HIP, "hydra_adjoint_V_antspace: %s", hipGetErrorString(e));
+  adjbig_table_kernel<<<std::min((nbl + 255) / 256, 1024), 256, 0, st>>>(bl_i, bl_j, nbl, nap, tab);
+  ctranspose_kernel<<<2048, 256, 0, st>>>(reinterpret_cast<const f64x2*>(z), nbl, nft, zt);
+  adjbig_frag_kernel<<<dim3((nsteps + 3) / 4, std::min(nft, 4096)), 256, 0, st>>>(
+      zt, tab, nbl, nft, nr, nsteps, zri, zs);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_V_antspace(fragments)");
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_big_kernel), lds)) return rc;
+  dim3 grid((ns + AB_SRC - 1) / AB_SRC, nsplit);
+  adjoint_V_big_kernel<<<grid, AB_THREADS, lds, st>>>(reinterpret_cast<const f64x2*>(V), nft, nant, ns, nr,
+                                               zri, zs, per, partial);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_V_antspace");
+  adjoint_reduce_kernel<<<(ns + 255) / 256, 256, 0, st>>>(partial, nsplit, ns, scale, add, out);
+  HYDRA_CHECK_LAUNCH("hydra_adjoint_V_antspace(reduce)");
+  return HYDRA_OK;
 }
 
 int hydra_debug_adjoint_mfma(int enable) {

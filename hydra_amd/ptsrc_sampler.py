@@ -68,8 +68,14 @@ class FactoredProj:
         self.rowtab = _dev.i32(self.rowtab_host)
         #: every antenna pair i<j exactly once -> the closed-form Gram applies (csrc/gram.hip)
         self.complete = _tables.is_complete_array(self.bl_i_host, self.bl_j_host, nant)
+        #: every pair listed once with i <= j: R^H z may run in antenna space for any array size
+        key = self.bl_i_host.astype(np.int64) * nant + self.bl_j_host
+        self.unique_upper = bool(np.all(self.bl_i_host <= self.bl_j_host)
+                                 and np.unique(key).size == key.size)
         #: set False to force the general (per-baseline weights) Gram kernel
         self.allow_uniform = True
+        #: set False to force the pair-loop R^H z for arrays of more than 64 antennas
+        self.antspace_adjoint = True
         #: |V[f,t,a,s]| independent of the antenna (set by the simulator for a single beam model)
         self.same_beam = bool(getattr(V, "hydra_same_beam", False))
 
@@ -111,9 +117,19 @@ class FactoredProj:
         """(Ns,) = scale * Re(R^H z) + add without materialising R."""
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
+        out = _dev.empty((ns,), torch.float64)
+        if 64 < nant <= 160 and self.unique_upper and self.antspace_adjoint:
+            # more than 64 antennas: antenna space on the matrix cores (csrc/gemv.hip,
+            # adjoint_V_big_kernel) instead of the pair loop on the vector units
+            nbytes = _dev._lib.query("hydra_adjoint_V_antspace_workspace_bytes", nf, nt, nant, nbl,
+                                     ns)
+            ws = _dev.workspace(nbytes)
+            _dev.call("hydra_adjoint_V_antspace", _dev.ptr(self.V), nf, nt, nant, ns,
+                      _dev.ptr(self.bl_i), _dev.ptr(self.bl_j), nbl, _dev.ptr(z), _dev.ptr(scale),
+                      _dev.ptr(add), _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
+            return out
         nbytes = _dev._lib.query("hydra_adjoint_V_workspace_bytes", nf, nt, nbl, ns)
         ws = _dev.workspace(nbytes)
-        out = _dev.empty((ns,), torch.float64)
         _dev.call("hydra_adjoint_V", _dev.ptr(self.V), nf, nt, nant, ns, _dev.ptr(self.bl_i),
                   _dev.ptr(self.bl_j), nbl, _dev.ptr(z), _dev.ptr(scale), _dev.ptr(add),
                   _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())

@@ -257,6 +257,18 @@ int hydra_adjoint_V(const double* V, int nf, int nt, int nant, int ns, const int
                     const int32_t* bl_j, int nbl, const double* z, const double* scale,
                     const double* add, double* out, void* workspace, size_t workspace_bytes,
                     void* stream);
+/* hydra_adjoint_V for arrays of ANY size in antenna space on the matrix cores (hydra_adjoint_V
+ * itself does so up to 64 antennas and loops over the baselines on the vector units beyond):
+ * W = Zc V per (f,t) with Zc[i][j] = conj(z_ij), then out[s] = scale[s] Re sum_i V_i,s conj(W_i,s)
+ * + add[s]; the voltages of a 32-source tile are staged in LDS, Zc is read in MFMA-fragment order.
+ * Precondition: every pair of (bl_i, bl_j) has i <= j and occurs once (a complete array, or any
+ * duplicate-free list in antenna order); Nant <= 160.   ptsrc_sampler.py:124,138; sh_sampler.py:376-384
+ * through the factored per-pixel operator.                                                        */
+size_t hydra_adjoint_V_antspace_workspace_bytes(int nf, int nt, int nant, int nbl, int ns);
+int hydra_adjoint_V_antspace(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
+                             const int32_t* bl_j, int nbl, const double* z, const double* scale,
+                             const double* add, double* out, void* workspace,
+                             size_t workspace_bytes, void* stream);
 /* Test hook: hydra_adjoint_V forms R^H z in antenna space on the matrix cores when Nant <= 64
  * (default) and with the pair-loop kernel otherwise; enable = 0 forces the pair loop.  Returns the
  * previous setting.  No counterpart in the reference.                                        */

@@ -543,3 +543,54 @@ def test_antenna_space_apply_matches_pair_loop_and_numpy(hy, nant, ns, nf, nt, k
               _dev.ptr(_dev.f64(x)), _dev.ptr(None), _dev.ptr(out), _dev.ptr(None), 0,
               _dev.stream_ptr())
     assert relerr(out.cpu().numpy(), np.einsum("ftbs,s->bft", R, x)) < 1e-12
+
+
+@pytest.mark.parametrize("hex_spec,ns,nf,nt", [((5, 9), 77, 3, 2), ((6, 11), 100, 2, 3),
+                                               ((7, 13), 45, 1, 5), ((7, 14), 33, 2, 1)])
+def test_antenna_space_adjoint_for_more_than_64_antennas(hex_spec, ns, nf, nt):
+    """hydra_adjoint_V_antspace (W = Zc V on the matrix cores, any array size) against the pair
+    loop and the oracle's Re(R^H z): 61, 91, 127 and 154 antennas (row blocks 4..10, odd and even
+    counts, antennas not a multiple of 16), sources not a multiple of the 32-wide tile, scale / add."""
+    import torch
+    import hydra_amd as hy
+    from oracle import beams as obeams, gcr_ptsrc, helpers
+    np.random.seed(41)
+    ant_pos = helpers.build_hex_array(hex_spec)
+    nant = len(ant_pos)
+    antpairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    ra, dec, amps = helpers.generate_random_ptsrc_catalogue(ns, (0.0, 1.0), (-0.6, 0.4))
+    freqs, times = np.linspace(100.0, 120.0, nf), np.linspace(0.2, 0.5, nt)
+    fluxes = helpers.get_flux_from_ptsrc_amp(amps, freqs, -2.7)
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    fac = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bh,
+                                              materialize=False)
+    assert fac.unique_upper
+    rng = np.random.RandomState(5)
+    nbl = len(antpairs)
+    z = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    scale, add = rng.rand(ns) + 0.5, rng.randn(ns)
+    zd = torch.as_tensor(z, device=fac.V.device)
+    sd, ad = torch.as_tensor(scale, device=fac.V.device), torch.as_tensor(add, device=fac.V.device)
+    fac.antspace_adjoint = False
+    want = fac.adjoint(zd, scale=sd, add=ad).cpu().numpy()
+    fac.antspace_adjoint = True
+    got = fac.adjoint(zd, scale=sd, add=ad).cpu().numpy()
+    if nant > 64:
+        assert relerr(got, want) < 1e-12
+    else:
+        assert np.array_equal(got, want)          # 61 antennas: the same (<= 64) kernel either way
+    bo = [obeams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    R = gcr_ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo).reshape(-1, ns)
+    ref = scale * (R.real.T @ z.reshape(-1).real + R.imag.T @ z.reshape(-1).imag) + add
+    assert operr(got, ref) < OP_TOL
+    # a list with autos and missing pairs (still i <= j, unique)
+    pairs2 = [(i, j) for i in range(nant) for j in range(i, nant) if (i + 2 * j) % 3 != 1]
+    fac2 = hy.ptsrc_sampler.calc_proj_operator(ra, dec, fluxes, ant_pos, pairs2, freqs, times, bh,
+                                               materialize=False)
+    z2 = rng.randn(len(pairs2), nf, nt) + 1j * rng.randn(len(pairs2), nf, nt)
+    z2d = torch.as_tensor(z2, device=fac.V.device)
+    fac2.antspace_adjoint = False
+    want2 = fac2.adjoint(z2d).cpu().numpy()
+    fac2.antspace_adjoint = True
+    got2 = fac2.adjoint(z2d).cpu().numpy()
+    assert relerr(got2, want2) < 1e-12
