@@ -193,6 +193,309 @@ gain_pairs_tiled_kernel(const f64x2* __restrict__ g, const double* __restrict__ 
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Streamed form: every weight crosses the fabric ONCE per operator application.
+//
+// A workgroup owns FT consecutive (f,t) samples and ALL antennas: the fields g (Nant x FT) and the
+// accumulators T (Nant x FT) live in LDS, and the weights of its samples arrive as one contiguous
+// stream in the order they are used.  That order ("stream layout", written once per operator by
+// gain_weights_stream_kernel) is
+//   chunk (FT samples) > sweep A (antennas a = 8A .. 8A+7) > sub-tile k > row r > column c' > ft
+// where sweep A holds the pairs (a, o) with o = 8A + 1 + c, c = 0 .. L_A - 1, L_A = Nant - 1 - 8A,
+// cut into sub-tiles of COLS = 256 / FT columns (the last one shorter, no padding in memory).
+// Slots with o <= a, a >= Nant or without a baseline hold 0; every unordered pair has exactly
+// one slot (sweep a / 8, row a % 8).  Padding: the 28 slots below the diagonal of each sweep, 2 %.
+//
+// A sub-tile (16 KiB) is copied to one of NBUF LDS buffers by LDS-DMA, NBUF - 1 sub-tiles ahead;
+// the loop holds no other vector-memory operation (the compiler answers a pending LDS-DMA with a
+// wait for vmcnt(0) at every dependent use, which would drain the pipeline), so all global reads
+// of g / sw and the writes of y sit before and after it.  Per sub-tile:
+//   column phase: thread (ft, c) adds sum_r W[r][c] g[8A + r] to T[o]     (one owner per entry)
+//   row phase:    wave w, rows 2w and 2w+1, lane (ft, j) sums W[r][c] g[o] over its columns in
+//                 registers across the sweep; an xor-shuffle reduction at the end of the sweep
+//                 and the owner lanes add the sums to T[a] behind the next barrier.
+// Fixed summation order, no atomics.  y = g sw + conj(T) with sw = sum_{b ∋ a} W_b precomputed by
+// one application to g = 1 (sw == NULL: y = conj(T)).
+template <int FT>
+struct GainStream {
+  static constexpr int COLS = 256 / FT;          // columns per sub-tile
+  static constexpr int TILE = 8 * COLS * FT;     // doubles per full sub-tile (= 2048)
+  static constexpr int JW = 64 / FT;             // column lanes per wave in the row phase
+};
+
+// doubles of one chunk before sweep A
+__host__ __device__ inline long long gs_sweep_base(int A, int nant, int ft) {
+  return 8LL * ft * ((long long)A * (nant - 1) - 4LL * A * (A - 1));
+}
+__host__ __device__ inline int gs_nsweeps(int nant) { return (nant - 1 + 7) / 8; }   // sweeps with L_A > 0
+// sub-tiles of one chunk
+__host__ __device__ inline int gs_ntiles(int nant, int cols) {
+  int n = 0;
+  for (int A = 0; A < gs_nsweeps(nant); ++A) n += (nant - 1 - 8 * A + cols - 1) / cols;
+  return n;
+}
+// The stream starts with one descriptor per sub-tile (the same for every chunk), so that the pair
+// kernel's loop reads its bookkeeping with one scalar load instead of recomputing it in every
+// wave: {byte offset in the chunk, columns | first-of-sweep << 16 | last-of-sweep << 17, first row
+// antenna, first column antenna}; header = descriptors padded to 256 B (in doubles below).
+__host__ __device__ inline long long gs_header_doubles(int nant, int cols) {
+  return (((long long)gs_ntiles(nant, cols) * 16 + 255) / 256) * 32;
+}
+
+__global__ void __launch_bounds__(256)
+gain_stream_desc_kernel(int nant, int ft, int4* __restrict__ desc) {
+  const int cols = 256 / ft;
+  int n = 0;
+  for (int A = 0; A < gs_nsweeps(nant); ++A) {
+    const int L = nant - 1 - 8 * A, nt = (L + cols - 1) / cols;
+    for (int k = threadIdx.x; k < nt; k += 256) {
+      const int nc = min(cols, L - k * cols);
+      const long long off = 8 * (gs_sweep_base(A, nant, ft) + (long long)k * 8 * cols * ft);
+      desc[n + k] = int4{(int)off, nc | (k == 0 ? 1 << 16 : 0) | (k == nt - 1 ? 1 << 17 : 0), 8 * A,
+                         8 * A + 1 + k * cols};
+    }
+    n += nt;
+  }
+}
+
+template <int FT>
+__global__ void __launch_bounds__(256)
+gain_weights_stream_kernel(const f64x2* __restrict__ mv, const double* __restrict__ w,
+                           const int32_t* __restrict__ pairb, int nant, int nft,
+                           double* __restrict__ Wt) {
+  using G = GainStream<FT>;
+  const int A = blockIdx.x, chunk = blockIdx.y;
+  const int L = nant - 1 - 8 * A;
+  const long long chunk_len = gs_sweep_base(gs_nsweeps(nant), nant, FT);
+  double* out = Wt + gs_header_doubles(nant, G::COLS) + (long long)chunk * chunk_len + gs_sweep_base(A, nant, FT);
+  const int total = 8 * L * FT;
+  for (int e = threadIdx.x; e < total; e += 256) {
+    int k = e / G::TILE, e2 = e - k * G::TILE;
+    int nc = min(G::COLS, L - k * G::COLS);
+    int r = e2 / (nc * FT), rem = e2 - r * nc * FT;
+    int c = rem / FT, ft = chunk * FT + (rem - c * FT);
+    int a = 8 * A + r, o = 8 * A + 1 + k * G::COLS + c;
+    double v = 0.0;
+    if (a < o && a < nant && ft < nft) {
+      int b = pairb[(size_t)a * nant + o];
+      if (b >= 0) {
+        f64x2 m = mv[(size_t)b * nft + ft];
+        v = (m.x * m.x + m.y * m.y) * (w ? w[(size_t)b * nft + ft] : 1.0);
+      }
+    }
+    out[e] = v;
+  }
+}
+
+// 8 waves: waves 0-3 run the column phase, waves 4-7 the row phase of the same sub-tile, each in a
+// loop of its own (both pass the same barriers).  A SIMD that holds one wave issues at most one
+// instruction every four cycles, scalar bookkeeping included: with both phases in the same four
+// waves and the tile bookkeeping recomputed per wave the loop body (300 instructions per 16 KiB)
+// took longer than the memory system needs to deliver the sub-tile.
+constexpr int GS_THREADS = 512;
+
+template <int FT, int NBUF>
+__global__ void __launch_bounds__(GS_THREADS)
+gain_pairs_stream_kernel(const f64x2* __restrict__ g, const double* __restrict__ Wt,
+                         const double* __restrict__ sw, int nant, int nft, int nt_total,
+                         long long header, long long chunk_len, f64x2* __restrict__ y) {
+  using G = GainStream<FT>;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nantp = ((nant + 7) & ~7) + G::COLS + 8;          // zero pad behind the last antenna
+  f64x2* s_g = reinterpret_cast<f64x2*>(smem);                // [nantp][FT]
+  f64x2* s_t = s_g + (size_t)nantp * FT;                      // [nantp][FT]
+  double* s_w = reinterpret_cast<double*>(s_t + (size_t)nantp * FT);   // [NBUF][8][COLS][FT]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int chunk = blockIdx.x, ft0 = chunk * FT;
+  const int4* __restrict__ desc = reinterpret_cast<const int4*>(Wt);
+  const char* wsrc = reinterpret_cast<const char*>(Wt + header + (long long)chunk * chunk_len);
+
+  // sub-tile pn -> LDS buffer pn % NBUF: this wave issues 2 of the 16 DMA instructions (row
+  // `wave`, both halves; lanes beyond the row's end stay off -- what they would fetch belongs to
+  // later rows -- except lane 0 of the second half, so that every wave issues exactly two
+  // instructions per sub-tile and the wait counts below are fixed)
+  typedef int i32x4 __attribute__((ext_vector_type(4)));
+  int pn = 0;
+  auto fetch = [&](const i32x4 d) {
+    const int rowbytes = (d.y & 0xffff) * FT * 8;
+    double* dst = s_w + (size_t)(pn % NBUF) * G::TILE + wave * (G::COLS * FT);
+    const char* src = wsrc + d.x + wave * rowbytes + lane * 16;
+    if (lane * 16 < rowbytes)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    if (lane * 16 + 1024 < rowbytes || lane == 0)
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + 1024),
+                                       (__attribute__((address_space(3))) void*)(dst + 128), 16, 0, 0);
+    ++pn;
+  };
+  // Descriptors come through scalar LOADS written out by hand (the compiler turns a plain read
+  // into a vector load here, and a vector load's wait drains the LDS-DMA queue to zero).
+  auto load_desc = [&](int i) {
+    i32x4 d;
+    const int4* p = desc + i;
+    asm volatile("s_load_dwordx4 %0, %1, 0x0\n\ts_waitcnt lgkmcnt(0)" : "=s"(d) : "s"(p) : "memory");
+    return d;
+  };
+  for (int i = 0; i < NBUF - 1 && pn < nt_total; ++i) fetch(load_desc(pn));
+
+  // fields into LDS; T starts at conj(g) sw, so that y = conj(T) at the end.  All global loads
+  // of a thread are issued before the first use.
+  {
+    constexpr int PER = 8;
+    for (int e0 = tid; e0 < nantp * FT; e0 += GS_THREADS * PER) {
+      f64x2 gv[PER];
+      double sv[PER];
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = e0 + u * GS_THREADS;
+        const int a = e / FT, ft = ft0 + (e - a * FT);
+        const bool ok = e < nantp * FT && a < nant && ft < nft;
+        const size_t o = ok ? (size_t)a * nft + ft : 0;
+        gv[u] = g[o];
+        sv[u] = sw ? sw[o] : 0.0;
+        if (!ok) { gv[u] = f64x2{0.0, 0.0}; sv[u] = 0.0; }
+      }
+#pragma unroll
+      for (int u = 0; u < PER; ++u) {
+        const int e = e0 + u * GS_THREADS;
+        if (e < nantp * FT) {
+          s_g[e] = gv[u];
+          s_t[e] = f64x2{gv[u].x * sv[u], -gv[u].y * sv[u]};
+        }
+      }
+    }
+  }
+  __syncthreads();                 // g, T in place (this also waits for the first fetches: once)
+
+  // sub-tile n has landed once at most (NBUF - 2) later sub-tiles of this wave are in flight; the
+  // descriptors of the sub-tile to multiply (returned) and of the one to fetch are loaded under
+  // the same wait
+  auto arrive = [&](int n) {
+    i32x4 dn, dp;
+    const int4* pc = desc + n;
+    const int4* pp = desc + min(pn, nt_total - 1);
+#define HYDRA_GS_ARRIVE(VM)                                                                        \
+  asm volatile("s_load_dwordx4 %0, %2, 0x0\n\ts_load_dwordx4 %1, %3, 0x0\n\t"                      \
+               "s_waitcnt vmcnt(" #VM ") lgkmcnt(0)\n\ts_barrier"                                  \
+               : "=&s"(dn), "=&s"(dp) : "s"(pc), "s"(pp) : "memory")
+    if (pn - n - 1 >= NBUF - 2) {
+      static_assert(NBUF >= 3 && NBUF <= 8, "wait counts below");
+      if (NBUF == 3) HYDRA_GS_ARRIVE(2);
+      if (NBUF == 4) HYDRA_GS_ARRIVE(4);
+      if (NBUF == 5) HYDRA_GS_ARRIVE(6);
+      if (NBUF == 6) HYDRA_GS_ARRIVE(8);
+      if (NBUF == 7) HYDRA_GS_ARRIVE(10);
+      if (NBUF == 8) HYDRA_GS_ARRIVE(12);
+    } else {
+      HYDRA_GS_ARRIVE(0);
+    }
+#undef HYDRA_GS_ARRIVE
+    if (pn < nt_total) fetch(dp);
+    return dn;
+  };
+
+  if (wave < 4) {
+    // column phase: thread (ft, c) adds sum_r W[r][c] g[A0 + r] to T[O0 + c]
+    const int cft = tid % FT, cc = tid / FT;
+    f64x2 ga[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) ga[r] = f64x2{0.0, 0.0};
+    for (int n = 0; n < nt_total; ++n) {
+      const i32x4 d = arrive(n);
+      const int nc = d.y & 0xffff;
+      if (d.y & (1 << 16)) {
+#pragma unroll
+        for (int r = 0; r < 8; ++r) ga[r] = s_g[(size_t)(d.z + r) * FT + cft];
+      }
+      if (cc < nc) {
+        const double* wb = s_w + (size_t)(n % NBUF) * G::TILE + tid;
+        double wc[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) wc[r] = wb[r * (G::COLS * FT)];
+        f64x2* tp = s_t + (size_t)(d.w + cc) * FT + cft;
+        f64x2 t = *tp;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          t.x += wc[r] * ga[r].x;
+          t.y += wc[r] * ga[r].y;
+        }
+        *tp = t;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+  } else {
+    // row phase: wave rw owns rows 2 rw, 2 rw + 1 of the sweep; lane (ft, j) sums its columns in
+    // registers across the sweep, xor-shuffle reduction at its end, the owner lanes add the sums
+    // to T behind the next barrier (no column of a later sweep touches these rows)
+    const int rw = wave - 4, rj = lane / FT;
+    f64x2 racc[2] = {f64x2{0.0, 0.0}, f64x2{0.0, 0.0}};
+    f64x2 rdone[2] = {f64x2{0.0, 0.0}, f64x2{0.0, 0.0}};
+    int rdone_a = -1;
+    auto flush = [&]() {
+      if (rdone_a >= 0 && lane < FT) {
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          f64x2* t = s_t + (size_t)(rdone_a + 2 * rw + rr) * FT + lane;
+          f64x2 v = *t;
+          *t = f64x2{v.x + rdone[rr].x, v.y + rdone[rr].y};
+        }
+      }
+      rdone_a = -1;
+    };
+    for (int n = 0; n < nt_total; ++n) {
+      const i32x4 d = arrive(n);
+      const int nc = d.y & 0xffff;
+      flush();
+      const double* wb = s_w + (size_t)(n % NBUF) * G::TILE + (2 * rw) * (G::COLS * FT) + lane;
+      const f64x2* gp = s_g + (size_t)d.w * FT + lane;
+      double wr[2][4];
+      f64x2 go[4];
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        go[k] = gp[k * 64];
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) wr[rr][k] = wb[rr * (G::COLS * FT) + k * 64];
+      }
+      if (nc < G::COLS) {                            // partial sub-tile: columns beyond nc hold junk
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+          if (k * G::JW + rj >= nc) wr[0][k] = wr[1][k] = 0.0;
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k)
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          racc[rr].x += wr[rr][k] * go[k].x;
+          racc[rr].y += wr[rr][k] * go[k].y;
+        }
+      if (d.y & (1 << 17)) {                         // end of the sweep: reduce over the j lanes
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+          double x = racc[rr].x, yv = racc[rr].y;
+#pragma unroll
+          for (int off = 32; off >= FT; off >>= 1) {
+            x += __shfl_xor(x, off, 64);
+            yv += __shfl_xor(yv, off, 64);
+          }
+          rdone[rr] = f64x2{x, yv};
+          racc[rr] = f64x2{0.0, 0.0};
+        }
+        rdone_a = d.z;
+      }
+    }
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)\n\ts_barrier" ::: "memory");
+    flush();
+  }
+  __syncthreads();
+  for (int e = tid; e < nant * FT; e += GS_THREADS) {
+    int a = e / FT, ft = ft0 + (e - a * FT);
+    if (ft >= nft) continue;
+    f64x2 t = s_t[e];
+    y[(size_t)a * nft + ft] = f64x2{t.x, -t.y};
+  }
+}
+
 // v[b,ft] = (x_i + conj(x_j)) * mv[b,ft]
 __global__ void __launch_bounds__(256)
 gain_proj_kernel(const f64x2* __restrict__ x, const int32_t* __restrict__ bl_i,
@@ -421,6 +724,99 @@ int hydra_gain_pairs_tiled(const double* g, int nvec, int nant, int nft, const d
       gain_pairs_tiled_kernel<1><<<grid, 256, 0, st>>>(gp, W, pairb, nant, nft, v0, nvec, yp);
     HYDRA_CHECK_LAUNCH("hydra_gain_pairs_tiled");
   }
+  return HYDRA_OK;
+}
+
+// FT and the LDS buffers of the streamed pair kernel for nant antennas; 0 = does not fit
+static int gain_stream_plan(int nant, int* nbuf, size_t* lds) {
+  const int fts[3] = {8, 4, 2};
+  for (int ft : fts) {
+    const int cols = 256 / ft;
+    const size_t nantp = (size_t)((nant + 7) & ~7) + cols + 8;
+    for (int nb = 4; nb >= 3; --nb) {   // (deeper prefetch measured no faster)
+      size_t need = 2 * nantp * ft * 16 + (size_t)nb * 2048 * 8;
+      if (need <= 160 * 1024) {
+        *nbuf = nb;
+        *lds = need;
+        return ft;
+      }
+    }
+  }
+  return 0;
+}
+
+size_t hydra_gain_stream_weight_count(int nant, int nft) {
+  int nbuf;
+  size_t lds;
+  int ft = (nant >= 2 && nft > 0) ? gain_stream_plan(nant, &nbuf, &lds) : 0;
+  if (!ft) return 0;
+  long long nchunk = (nft + ft - 1) / ft;
+  return (size_t)(gs_header_doubles(nant, 256 / ft) +
+                  nchunk * gs_sweep_base(gs_nsweeps(nant), nant, ft)) + 512;   // + DMA over-read slack
+}
+
+int hydra_gain_weights_stream(const double* model_vis, const double* inv_noise, int nbl, int nant,
+                              int nft, const int32_t* pairb, double* Wt, void* stream) {
+  HYDRA_CHECK_ARG(model_vis && pairb && Wt && nbl > 0 && nant >= 2 && nft > 0,
+                  "hydra_gain_weights_stream: bad arguments");
+  int nbuf;
+  size_t lds;
+  int ft = gain_stream_plan(nant, &nbuf, &lds);
+  HYDRA_CHECK_ARG(ft != 0, "hydra_gain_weights_stream: %d antennas do not fit the streamed kernel", nant);
+  const int nchunk = (nft + ft - 1) / ft;
+  HYDRA_CHECK_ARG(nchunk <= 65535, "hydra_gain_weights_stream: nft too large");
+  hipStream_t st = as_stream(stream);
+  size_t count = hydra_gain_stream_weight_count(nant, nft);
+  hipError_t e = hipMemsetAsync(Wt + (count - 512), 0, 512 * sizeof(double), st);
+  if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_gain_weights_stream: %s", hipGetErrorString(e));
+  e = hipMemsetAsync(Wt, 0, (size_t)gs_header_doubles(nant, 256 / ft) * sizeof(double), st);
+  if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_gain_weights_stream: %s", hipGetErrorString(e));
+  gain_stream_desc_kernel<<<1, 256, 0, st>>>(nant, ft, reinterpret_cast<int4*>(Wt));
+  dim3 grid(gs_nsweeps(nant), nchunk);
+  const f64x2* mv = reinterpret_cast<const f64x2*>(model_vis);
+  if (ft == 8) gain_weights_stream_kernel<8><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
+  else if (ft == 4) gain_weights_stream_kernel<4><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
+  else gain_weights_stream_kernel<2><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
+  HYDRA_CHECK_LAUNCH("hydra_gain_weights_stream");
+  return HYDRA_OK;
+}
+
+int hydra_gain_pairs_stream(const double* g, int nant, int nft, const double* Wt, const double* sw,
+                            double* y, void* stream) {
+  HYDRA_CHECK_ARG(g && Wt && y && nant >= 2 && nft > 0, "hydra_gain_pairs_stream: bad arguments");
+  int nbuf;
+  size_t lds;
+  int ft = gain_stream_plan(nant, &nbuf, &lds);
+  HYDRA_CHECK_ARG(ft != 0, "hydra_gain_pairs_stream: %d antennas do not fit the streamed kernel", nant);
+  const int nchunk = (nft + ft - 1) / ft;
+  const int nt_total = gs_ntiles(nant, 256 / ft);
+  const long long header = gs_header_doubles(nant, 256 / ft);
+  const long long chunk_len = gs_sweep_base(gs_nsweeps(nant), nant, ft);
+  hipStream_t st = as_stream(stream);
+  const f64x2* gp = reinterpret_cast<const f64x2*>(g);
+  f64x2* yp = reinterpret_cast<f64x2*>(y);
+#define HYDRA_GS_LAUNCH(FT_, NB_)                                                                  \
+  do {                                                                                             \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gain_pairs_stream_kernel<FT_, NB_>), lds)) \
+      return rc;                                                                                   \
+    gain_pairs_stream_kernel<FT_, NB_><<<nchunk, GS_THREADS, lds, st>>>(                          \
+        gp, Wt, sw, nant, nft, nt_total, header, chunk_len, yp);        \
+  } while (0)
+#define HYDRA_GS_CASE(FT_)                                                                         \
+  switch (nbuf) {                                                                                  \
+    case 3: HYDRA_GS_LAUNCH(FT_, 3); break;                                                        \
+    case 4: HYDRA_GS_LAUNCH(FT_, 4); break;                                                        \
+    case 5: HYDRA_GS_LAUNCH(FT_, 5); break;                                                        \
+    case 6: HYDRA_GS_LAUNCH(FT_, 6); break;                                                        \
+    case 7: HYDRA_GS_LAUNCH(FT_, 7); break;                                                        \
+    default: HYDRA_GS_LAUNCH(FT_, 8); break;                                                       \
+  }
+  if (ft == 8) { HYDRA_GS_CASE(8) }
+  else if (ft == 4) { HYDRA_GS_CASE(4) }
+  else { HYDRA_GS_CASE(2) }
+#undef HYDRA_GS_CASE
+#undef HYDRA_GS_LAUNCH
+  HYDRA_CHECK_LAUNCH("hydra_gain_pairs_stream");
   return HYDRA_OK;
 }
 

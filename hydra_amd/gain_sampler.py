@@ -174,12 +174,37 @@ class GainOperator:
         assert int(np.prod(mv.shape[1:])) == self.nft
         self.s = _dev.f64(pspec_sqrt)
         assert tuple(self.s.shape) == (self.nmodes,)
-        self.W = _dev.empty((self.nbl, self.nft), torch.float64)
-        _dev.call("hydra_gain_weights", _dev.ptr(mv), _dev.ptr(w), self.nbl * self.nft,
-                  _dev.ptr(self.W), _dev.stream_ptr())
+        self._mv, self._w, self._W = mv, w, None
         self.n = 2 * self.idx.nants * self.nmodes
         #: use the LDS-tiled pair kernel when the pair list has no duplicates
         self.tiled = True
+        #: single vectors go through the streamed pair kernel (every weight read once per
+        #: application) when the pair list has neither duplicates nor auto-correlations
+        nants = self.idx.nants
+        count = _dev._lib.query("hydra_gain_stream_weight_count", nants, self.nft)
+        self.stream = bool(self.idx.pair_table is not None and count > 0
+                           and not np.any(self.idx.i1 == self.idx.i2))
+        self.Wt = self.sw = None
+        if self.stream:
+            st = _dev.stream_ptr()
+            self.Wt = _dev.empty((count,), torch.float64)
+            _dev.call("hydra_gain_weights_stream", _dev.ptr(mv), _dev.ptr(w), self.nbl, nants,
+                      self.nft, _dev.ptr(self.idx.pair_dev()), _dev.ptr(self.Wt), st)
+            ones = torch.ones((nants, self.nft), dtype=torch.complex128, device=mv.device)
+            y1 = _dev.empty((nants, self.nft), torch.complex128)
+            _dev.call("hydra_gain_pairs_stream", _dev.ptr(ones), nants, self.nft,
+                      _dev.ptr(self.Wt), _dev.ptr(None), _dev.ptr(y1), st)
+            self.sw = y1.real.contiguous()
+
+    @property
+    def W(self):
+        """The fused weight |model_vis|^2 N^-1 as (Nbl, Nft) (gain_sampler.py:278-284), for the
+        pair kernels that read it by baseline; built on first use."""
+        if self._W is None:
+            self._W = _dev.empty((self.nbl, self.nft), torch.float64)
+            _dev.call("hydra_gain_weights", _dev.ptr(self._mv), _dev.ptr(self._w),
+                      self.nbl * self.nft, _dev.ptr(self._W), _dev.stream_ptr())
+        return self._W
 
     def local(self, X, add=None):
         X = _dev.f64(X)
@@ -195,7 +220,10 @@ class GainOperator:
                   _dev.ptr(self.F), _dev.ptr(self.s), _dev.ptr(g), st)
         y = _dev.empty((nvec, nants, nft), torch.complex128)
         pairb = self.idx.pair_dev() if self.tiled else None
-        if pairb is not None:
+        if self.stream and nvec == 1:
+            _dev.call("hydra_gain_pairs_stream", _dev.ptr(g), nants, nft, _dev.ptr(self.Wt),
+                      _dev.ptr(self.sw), _dev.ptr(y), st)
+        elif pairb is not None:
             _dev.call("hydra_gain_pairs_tiled", _dev.ptr(g), nvec, nants, nft, _dev.ptr(self.W),
                       self.nbl, _dev.ptr(pairb), _dev.ptr(y), st)
         else:

@@ -444,6 +444,24 @@ int hydra_gain_pairs(const double* g, int nvec, int nant, int nft, const double*
 int hydra_gain_pairs_tiled(const double* g, int nvec, int nant, int nft, const double* W, int nbl,
                            const int32_t* pairb, double* y, void* stream);
 
+/* The same operator (gain_sampler.py:278-284) with every weight read ONCE per application:
+ * a workgroup owns a few (f,t) samples and all antennas (fields and sums in LDS) and streams its
+ * weights, stored in the order of use, through LDS-DMA buffers (csrc/gain.hip, "streamed form").
+ * For pair lists without duplicates and without auto-correlations, up to about 1600 antennas.
+ *   hydra_gain_stream_weight_count : doubles of the stream layout Wt (0: Nant does not fit)
+ *   hydra_gain_weights_stream      : Wt <- |model_vis|^2 inv_noise (inv_noise NULL: 1), the
+ *                                    fused weight of gain_sampler.py:278-284, in stream layout;
+ *                                    pairb as for hydra_gain_pairs_tiled
+ *   hydra_gain_pairs_stream        : y[a] = g[a] sw[a] + conj(sum_o W[{a,o}] g[o]) for ONE field
+ *                                    g (Nant,Nft) c128; sw (Nant,Nft) f64 = sum_{b in adj(a)} W[b]
+ *                                    (what an application to g = 1 with sw = NULL returns in
+ *                                    Re y); sw NULL: the second term alone                       */
+size_t hydra_gain_stream_weight_count(int nant, int nft);
+int hydra_gain_weights_stream(const double* model_vis, const double* inv_noise, int nbl, int nant,
+                              int nft, const int32_t* pairb, double* Wt, void* stream);
+int hydra_gain_pairs_stream(const double* g, int nant, int nft, const double* Wt, const double* sw,
+                            double* y, void* stream);
+
 /* apply_proj: out[b,f,t] = (x_i + conj(x_j)) model_vis[b,f,t]    gain_sampler.py:81-106 */
 int hydra_gain_proj(const double* x, const int32_t* bl_i, const int32_t* bl_j, int nbl,
                     const double* model_vis, int nft, double* out, void* stream);

@@ -148,6 +148,13 @@ def test_c4_pair_kernels_agree_and_match_oracle_on_slices(c4):
               int(idx.adj_b.size), _dev.ptr(y_c), _dev.stream_ptr())
     scale = float(y_c.abs().max())
     assert float((y_t - y_c).abs().max()) <= 1e-12 * scale      # summation order differs
+    # streamed form (every weight read once): one field per call
+    assert op.stream
+    y_s = _dev.empty((2, nant, nft), torch.complex128)
+    for v in range(2):
+        _dev.call("hydra_gain_pairs_stream", _dev.ptr(g[v]), nant, nft, _dev.ptr(op.Wt),
+                  _dev.ptr(op.sw), _dev.ptr(y_s[v]), _dev.stream_ptr())
+    assert float((y_s - y_c).abs().max()) <= 1e-12 * scale
     # oracle on (f,t) slices: the pair stage is point-wise in (f,t)
     i1, i2 = gcr_gain.bl_indices(c4["ants"], c4["antpairs"])
     fsel, tsel = np.array([0, 31, 63]), np.array([0, 17, 63])
@@ -165,7 +172,7 @@ def test_c4_pair_kernels_agree_and_match_oracle_on_slices(c4):
     w_s = c4["w"].reshape(op.nbl, nft)[:, ftd].cpu().numpy().reshape(op.nbl, 3, 3)
     y_ref = gcr_gain.apply_proj_conj(gcr_gain.apply_proj(g_ref, i1, i2, mv_s) * w_s, i1, i2, mv_s,
                                      (nant, 3, 3))
-    for y in (y_t, y_c):
+    for y in (y_t, y_c, y_s):
         y_got = y[0][:, ftd].cpu().numpy().reshape(nant, 3, 3)
         assert relerr(y_got, y_ref) < 1e-10
         assert elem_err(y_got, y_ref) <= 1.0

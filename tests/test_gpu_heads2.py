@@ -594,3 +594,51 @@ def test_antenna_space_adjoint_for_more_than_64_antennas(hex_spec, ns, nf, nt):
     fac2.antspace_adjoint = True
     got2 = fac2.adjoint(z2d).cpu().numpy()
     assert relerr(got2, want2) < 1e-12
+
+
+@pytest.mark.parametrize("nant,nft", [(380, 21), (430, 10), (9, 3)])
+def test_streamed_gain_pairs_layouts(hy, nant, nft):
+    """hydra_gain_pairs_stream in its other layouts -- 8 samples per workgroup with three LDS
+    buffers (345-408 antennas), 4 samples per workgroup (beyond), a single sweep -- against the
+    adjacency kernel on a pair list with holes (gain_sampler.py:278-284)."""
+    import torch
+    from hydra_amd import _dev, gain_sampler as gs
+    rng = np.random.RandomState(nant)
+    pairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    keep = rng.rand(len(pairs)) > 0.2
+    pairs = [p for p, k in zip(pairs, keep) if k]
+    nbl = len(pairs)
+    i1 = np.array([p[0] for p in pairs], dtype=np.int32)
+    i2 = np.array([p[1] for p in pairs], dtype=np.int32)
+    idx = gs._Index(i1, i2, nant)
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(nant)
+    mv = torch.randn((nbl, nft), dtype=torch.complex128, device=dev, generator=gen)
+    w = 1.0 + torch.rand((nbl, nft), dtype=torch.float64, device=dev, generator=gen)
+    g = torch.randn((1, nant, nft), dtype=torch.complex128, device=dev, generator=gen)
+    st = _dev.stream_ptr()
+    W = _dev.empty((nbl, nft), torch.float64)
+    _dev.call("hydra_gain_weights", _dev.ptr(mv), _dev.ptr(w), nbl * nft, _dev.ptr(W), st)
+    _, _, adj_ptr, adj_b, adj_o, _ = idx.dev()
+    y_c = _dev.empty((1, nant, nft), torch.complex128)
+    _dev.call("hydra_gain_pairs", _dev.ptr(g), 1, nant, nft, _dev.ptr(W), nbl,
+              _dev.host_ptr(idx.adj_ptr), _dev.ptr(adj_ptr), _dev.ptr(adj_b), _dev.ptr(adj_o),
+              int(idx.adj_b.size), _dev.ptr(y_c), st)
+    count = _dev._lib.query("hydra_gain_stream_weight_count", nant, nft)
+    assert count > 0
+    Wt = _dev.empty((count,), torch.float64)
+    _dev.call("hydra_gain_weights_stream", _dev.ptr(mv), _dev.ptr(w), nbl, nant, nft,
+              _dev.ptr(idx.pair_dev()), _dev.ptr(Wt), st)
+    ones = torch.ones((nant, nft), dtype=torch.complex128, device=dev)
+    y1 = _dev.empty((nant, nft), torch.complex128)
+    _dev.call("hydra_gain_pairs_stream", _dev.ptr(ones), nant, nft, _dev.ptr(Wt), _dev.ptr(None),
+              _dev.ptr(y1), st)
+    sw = y1.real.contiguous()
+    y_s = _dev.empty((nant, nft), torch.complex128)
+    _dev.call("hydra_gain_pairs_stream", _dev.ptr(g), nant, nft, _dev.ptr(Wt), _dev.ptr(sw),
+              _dev.ptr(y_s), st)
+    scale = float(y_c.abs().max())
+    assert float((y_s - y_c[0]).abs().max()) <= 1e-12 * scale
+    # every weight sits in exactly one slot of the stream layout
+    assert abs(float(Wt.sum()) - float(W.sum())) <= 1e-12 * float(W.sum())
+    assert _dev._lib.query("hydra_gain_stream_weight_count", 1800, nft) == 0

@@ -545,7 +545,13 @@ def test_gain_operator_batched_matches_oracle_and_solves(hy, orc, hex_spec, nf, 
     for v in range(nvec):
         ref = gcr_gain.apply_operator(X[v], w, ps, i1, i2, mv, Fb)
         assert operr(Y[v], ref) < OP_TOL
+    assert op.stream                                       # single vectors: streamed pair kernel
+    assert relerr(op.apply(X[0]), Y[0]) < 1e-13
+    ref0 = gcr_gain.apply_operator(X[0], w, ps, i1, i2, mv, Fb)
+    assert operr(op.apply(X[0]), ref0) < OP_TOL
+    op.stream = False
     assert relerr(op.apply(X[0]), Y[0]) < 1e-14                             # single-vector path
+    op.stream = True
     op.tiled = False                                                        # CSR adjacency kernel
     assert relerr(op.apply(X), Y) < 1e-13
     op.tiled = True

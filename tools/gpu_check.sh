@@ -2,7 +2,7 @@
 # One GPU-box visit: parity tests, the bench line, the rocprofv3 kernel summary and the PMC
 # traffic passes of the same bench command.  Every GPU step has its own time limit and the
 # steps are chained: the first failure ends the script.
-#   gpurun --timeout 1100 -- 'bash tools/gpu_check.sh r1 c2 [extra bench flags]'
+#   gpurun --timeout 1100 -- '[SKIP_TESTS=1] bash tools/gpu_check.sh r1 c2 [extra bench flags]'
 set -eo pipefail
 TAG=${1:-r1}
 CFG=${2:-c2}
@@ -11,9 +11,11 @@ OUT=gpurun_out/$TAG
 mkdir -p "$OUT"
 export TMPDIR=/tmp
 ROOT=$(pwd)
+if [ -z "$SKIP_TESTS" ]; then
 timeout -k 10 600 python -u -m pytest tests -m gpu -x -q --timeout 120 --timeout-method thread \
     > "$OUT/pytest_gpu.log" 2>&1 || { tail -30 "$OUT/pytest_gpu.log"; exit 1; }
 tail -3 "$OUT/pytest_gpu.log"
+fi
 timeout -k 10 600 python -u bench.py --config "$CFG" $EXTRA > "$OUT/bench_$CFG.json" 2> "$OUT/bench_$CFG.err" \
     || { tail -30 "$OUT/bench_$CFG.err"; exit 1; }
 cat "$OUT/bench_$CFG.json"
