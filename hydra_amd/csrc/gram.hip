@@ -19,8 +19,6 @@
 // tile to a slab and a second kernel sums the slabs in a fixed order (bitwise reproducible,
 // no atomics), mirrors the triangle and applies the prior epilogue.
 #include <algorithm>
-#include <type_traits>
-
 #include "common.h"
 
 namespace hydra {
@@ -802,38 +800,60 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
           P3[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         }
     }
-    auto kstep = [&](int kk) {   // one k-step (4 antennas)
+    // One k-step (4 antennas).  All five operand reads go out first and are waited for once: with
+    // the B operands read between the two column bursts a k-step had three exposed LDS round
+    // trips, and the two waves of a SIMD, running the same instruction stream in step, spent them
+    // idle together.  Only in the k-step that holds the q row (SAMEBEAM) the q lane is masked out
+    // of the products and the rank-one term applied; every other k-step uses the operands as read
+    // (the masks used to run in all of them: 20 VALU ops and 18 registers).
+    auto kstep = [&](int kk) {
       const f64x2* up = ub + kk * 4 * K3_W;
-      bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));
-      bool qlane = qstep && (kr == (qrow & 3));
-      double ax[3], ay[3], as[3], nq[3];
+      const bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));   // uniform
+      f64x2 a[3], b[2];
 #pragma unroll
-      for (int rb = 0; rb < 3; ++rb) {
-        f64x2 a = up[offA + rb * 16];
-        if (SAMEBEAM) {
-          nq[rb] = qlane ? -a.x : 0.0;
-          if (qlane) a = f64x2{0.0, 0.0};
-        } else {
-          nq[rb] = -(a.x * a.x + a.y * a.y);
+      for (int rb = 0; rb < 3; ++rb) a[rb] = up[offA + rb * 16];
+#pragma unroll
+      for (int cb = 0; cb < 2; ++cb) b[cb] = up[offB + cb * 16];
+      double nq[3] = {0.0, 0.0, 0.0};
+      if (SAMEBEAM) {
+        if (qstep) {
+          // a real branch (the empty asm keeps it from being turned into selects): it touches
+          // operand registers only, never an accumulator
+          asm volatile("" ::: "memory");
+          const bool qlane = kr == (qrow & 3);
+#pragma unroll
+          for (int rb = 0; rb < 3; ++rb) {
+            nq[rb] = qlane ? -a[rb].x : 0.0;
+            if (qlane) a[rb] = f64x2{0.0, 0.0};
+          }
         }
-        ax[rb] = a.x; ay[rb] = a.y; as[rb] = a.x + a.y;
+      } else {
+#pragma unroll
+        for (int rb = 0; rb < 3; ++rb) nq[rb] = -(a[rb].x * a[rb].x + a[rb].y * a[rb].y);
       }
+      double as[3];
+#pragma unroll
+      for (int rb = 0; rb < 3; ++rb) as[rb] = a[rb].x + a[rb].y;
 #pragma unroll
       for (int cb = 0; cb < 2; ++cb) {
-        f64x2 b = up[offB + cb * 16];
-        double bd = b.x - b.y;
-        double bq = SAMEBEAM ? b.x : b.x * b.x + b.y * b.y;
+        const double bd = b[cb].x - b[cb].y;
 #pragma unroll
         for (int rb = 0; rb < 3; ++rb) {
-          P1[rb][cb] = mfma(ax[rb], b.x, P1[rb][cb]);
-          P2[rb][cb] = mfma(ay[rb], b.y, P2[rb][cb]);
+          P1[rb][cb] = mfma(a[rb].x, b[cb].x, P1[rb][cb]);
+          P2[rb][cb] = mfma(a[rb].y, b[cb].y, P2[rb][cb]);
           P3[rb][cb] = mfma(as[rb], bd, P3[rb][cb]);
-          if (!SAMEBEAM) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
         }
-        if (SAMEBEAM && qstep) {
+        if (!SAMEBEAM) {
+          const double bq = b[cb].x * b[cb].x + b[cb].y * b[cb].y;
 #pragma unroll
           for (int rb = 0; rb < 3; ++rb) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
         }
+      }
+      if (SAMEBEAM && qstep) {
+#pragma unroll
+        for (int cb = 0; cb < 2; ++cb)
+#pragma unroll
+          for (int rb = 0; rb < 3; ++rb) G[rb][cb] = mfma(nq[rb], b[cb].x, G[rb][cb]);
       }
     };
 #pragma unroll
