@@ -475,16 +475,67 @@ def case_symreduce(comm):
     comm.barrier()
 
 
+def case_nccl1(comm):
+    """Every collective of _dist.Comm on RCCL itself, with the one rank a 1-GPU box can hold:
+    the nccl-only branches (GPU-resident numpy staging, reduce_scatter_tensor,
+    all_gather_into_tensor, sub-groups) run with real communicators and kernels, so the first
+    multi-GPU launch is not also the first RCCL call."""
+    assert comm.backend == "nccl" and comm.Get_size() == 1
+    dev = torch.device("cuda")
+    x = torch.arange(12, dtype=torch.float64, device=dev).reshape(3, 4)
+    assert torch.equal(comm.allreduce_(x.clone()), x)
+    assert torch.equal(comm.allreduce_(x.clone(), op="max"), x)
+    assert torch.equal(comm.reduce_(x.clone(), root=0), x)
+    assert torch.equal(comm.bcast_(x.clone(), root=0), x)
+    z = torch.randn(5, dtype=torch.complex128, device=dev)
+    assert torch.equal(comm.allreduce_(z.clone()), z)
+    h = np.arange(6.0)
+    comm.allreduce_(h)                               # numpy buffer staged through the GPU
+    assert np.array_equal(h, np.arange(6.0))
+    hb = np.arange(4.0) + 1j
+    comm.Bcast(hb, root=0)
+    assert np.array_equal(hb, np.arange(4.0) + 1j)
+    parts = comm.allgather(x)
+    assert len(parts) == 1 and torch.equal(parts[0], x)
+    A = torch.randn(8, 8, dtype=torch.float64, device=dev)
+    A = (A + A.T).contiguous()
+    rows = comm.reduce_rows_(A.clone())              # reduce_scatter_tensor
+    assert torch.equal(rows, A)
+    assert torch.equal(comm.reduce_sym_(A.clone(), root=0), A)
+    assert torch.equal(comm.allreduce_sym_(A.clone()), A)
+    v = torch.arange(7, dtype=torch.float64, device=dev)
+    assert torch.equal(comm.allgather_rows(v, 7)[:7], v)
+    sub = comm.Create([0])
+    assert sub is not None and sub.Get_size() == 1
+    assert torch.equal(sub.allreduce_(x.clone()), x)
+    # the root-driven CG of the SH head (example.py:1014-1052) over RCCL
+    from hydra_amd import linear_solver
+    rng = np.random.RandomState(0)
+    M = rng.randn(40, 12)
+    Ad = torch.as_tensor(M.T @ M + np.eye(12), device=dev)
+    b = torch.as_tensor(rng.randn(12), device=dev)
+    xs = linear_solver.cg(None, b, linear_op=lambda p: Ad @ p, comm=comm, abs_tol=1e-12)
+    assert float(torch.linalg.norm(Ad @ xs - b)) < 1e-9
+    comm.barrier()
+
+
 if __name__ == "__main__":
     case = sys.argv[1]
     logdir = sys.argv[2] if len(sys.argv) > 2 else None
-    comm = _dist.init_from_env(backend="gloo")
+    if case == "nccl1":
+        import torch.distributed as dist
+        torch.cuda.set_device(0)
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl")
+        comm = _dist.Comm()
+    else:
+        comm = _dist.init_from_env(backend="gloo")
     assert comm is not None, "run under torch.distributed.run with WORLD_SIZE > 1"
     try:
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
          "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
          "rowshard": case_rowshard, "shmpi": case_shmpi, "gainmpi": case_gainmpi,
-         "symreduce": case_symreduce, "driver": case_driver}[case](comm)
+         "symreduce": case_symreduce, "driver": case_driver, "nccl1": case_nccl1}[case](comm)
     except BaseException:
         import traceback
         if logdir:

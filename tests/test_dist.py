@@ -102,3 +102,9 @@ def test_driver_on_a_2x2_chunk_grid_with_mpicg_world4():
 @pytest.mark.gpu
 def test_driver_with_frequency_chunks_world2():
     _run("driver", 2)
+
+
+@pytest.mark.gpu
+def test_rccl_collectives_world1():
+    """The nccl branches of _dist.Comm on a real RCCL communicator (one rank: a 1-GPU box)."""
+    _run("nccl1", 1)
