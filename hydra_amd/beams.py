@@ -216,3 +216,64 @@ class GriddedBeam:
         out = self.device_response(np.asarray(az_array, dtype=np.float64),
                                    np.asarray(za_array, dtype=np.float64), freq_array)
         return out.cpu().numpy()[np.newaxis, np.newaxis, :, :]
+
+
+class HealpixBeam:
+    """Power beam tabulated on a HEALPix map (RING ordering) per frequency -- the role of a
+    pyuvdata ``UVBeam`` in healpix coordinates with ``interpolation_function =
+    "healpix_simple"`` and ``freq_interp_kind = "linear"``
+    (scripts/precompute_response_sh_singlefreq_general.py:106-110): bilinear interpolation over
+    the four nearest pixels and linear interpolation between channels, evaluated on the GPU
+    (``hydra_beam_healpix``)."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, freqs_hz, power):
+        self.freqs = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
+        power = np.atleast_2d(np.asarray(power, dtype=np.float64))
+        if power.shape[0] != self.freqs.size:
+            raise ValueError("power must have shape (Nfreq, Npix)")
+        self.nside = int(round(np.sqrt(power.shape[1] / 12.0)))
+        if 12 * self.nside ** 2 != power.shape[1]:
+            raise ValueError("Npix is not 12 nside^2")
+        if self.freqs.size > 1 and np.any(np.diff(self.freqs) <= 0):
+            raise ValueError("tabulated frequencies must increase")
+        self.power = power
+        self._maps_d = None
+
+    def _channel_weights(self, freqs_hz):
+        """Neighbouring tabulated channels and the weight of the upper one (scipy interp1d
+        'linear': a frequency outside the table is an error)."""
+        f = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
+        if self.freqs.size == 1:
+            z = np.zeros(f.size, dtype=np.int32)
+            return z, z, np.zeros(f.size)
+        if f.min() < self.freqs[0] or f.max() > self.freqs[-1]:
+            raise ValueError("A value in freq_array is outside the tabulated frequency range.")
+        hi = np.clip(np.searchsorted(self.freqs, f, side="left"), 1, self.freqs.size - 1)
+        lo = hi - 1
+        w = (f - self.freqs[lo]) / (self.freqs[hi] - self.freqs[lo])
+        return lo.astype(np.int32), hi.astype(np.int32), w
+
+    def device_response(self, az, za, freqs_hz):
+        """Power values (Nfreq,) + az.shape as a GPU tensor; ``az``, ``za`` GPU tensors."""
+        import torch
+        from . import _dev
+        if self._maps_d is None:
+            self._maps_d = _dev.f64(self.power)
+        lo, hi, w = self._channel_weights(freqs_hz)
+        az_d, za_d = _dev.f64(az), _dev.f64(za)
+        out = _dev.empty((lo.size,) + tuple(az_d.shape), torch.float64)
+        lo_d, hi_d, w_d = _dev.i32(lo), _dev.i32(hi), _dev.f64(w)
+        _dev.call("hydra_beam_healpix", _dev.ptr(self._maps_d), self.freqs.size, self.nside,
+                  _dev.ptr(lo_d), _dev.ptr(hi_d), _dev.ptr(w_d), lo.size, _dev.ptr(za_d),
+                  _dev.ptr(az_d), az_d.numel(), _dev.ptr(out), _dev.stream_ptr())
+        return out
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        """Host-array interface of the beam protocol (evaluated on the GPU as well)."""
+        out = self.device_response(np.asarray(az_array, dtype=np.float64),
+                                   np.asarray(za_array, dtype=np.float64), freq_array)
+        return out.cpu().numpy()[np.newaxis, np.newaxis, :, :]

@@ -240,6 +240,120 @@ bspline2d_kernel(const double* __restrict__ tx, int nx, const double* __restrict
   }
 }
 
+// HEALPix (RING) bilinear interpolation, Healpix_Base::get_interpol: the two iso-latitude rings
+// around theta, two pixels on each, weights linear in phi along the rings and in theta between
+// them; in the polar caps the four pixels of the first / last ring stand in for the missing ring.
+struct HpRing {
+  long long start;
+  int npix;
+  double theta;
+  bool shifted;
+};
+__device__ inline HpRing hp_ring_info(int nside, int ring) {
+  const long long npix = 12LL * nside * nside, ncap = 2LL * nside * (nside - 1);
+  const double fact2 = 4.0 / (double)npix, fact1 = (2 * nside) * fact2;
+  const int north = ring > 2 * nside ? 4 * nside - ring : ring;
+  HpRing r;
+  double costh;
+  if (north < nside) {
+    double tmp = (double)north * north * fact2;
+    costh = 1.0 - tmp;
+    double sinth = sqrt(fmax((1.0 - costh) * (1.0 + costh), 0.0));
+    r.theta = atan2(sinth, costh);
+    r.npix = 4 * north;
+    r.shifted = true;
+    r.start = 2LL * north * (north - 1);
+  } else {
+    costh = (2 * nside - north) * fact1;
+    r.theta = acos(fmin(fmax(costh, -1.0), 1.0));
+    r.npix = 4 * nside;
+    r.shifted = ((north - nside) & 1) == 0;
+    r.start = ncap + (long long)(north - nside) * r.npix;
+  }
+  if (north != ring) {
+    r.theta = M_PI - r.theta;
+    r.start = npix - r.start - r.npix;
+  }
+  return r;
+}
+
+// out[f, p] = (1 - wf) sum_k wgt_k map[f0][pix_k] + wf sum_k wgt_k map[f1][pix_k]
+__global__ void __launch_bounds__(256)
+beam_healpix_kernel(const double* __restrict__ maps, int nside, const int32_t* __restrict__ f0,
+                    const int32_t* __restrict__ f1, const double* __restrict__ wf, int nf,
+                    const double* __restrict__ za, const double* __restrict__ az, size_t npts,
+                    double* __restrict__ out) {
+  size_t p = blockIdx.x * (size_t)blockDim.x + threadIdx.x;
+  if (p >= npts) return;
+  const long long npix = 12LL * nside * nside;
+  const double theta = za[p];
+  double phi = fmod(az[p], 2.0 * M_PI);
+  if (phi < 0.0) phi += 2.0 * M_PI;
+  const double z = cos(theta), azz = fabs(z);
+  int ir1;
+  if (azz <= 2.0 / 3.0) {
+    ir1 = (int)(nside * (2.0 - 1.5 * z));
+  } else {
+    int ic = (int)(nside * sqrt(3.0 * (1.0 - azz)));
+    ir1 = z > 0 ? ic : 4 * nside - ic - 1;
+  }
+  const int ir2 = ir1 + 1;
+  long long pix[4] = {0, 0, 0, 0};
+  double wgt[4] = {0.0, 0.0, 0.0, 0.0}, th[2] = {0.0, 0.0};
+#pragma unroll
+  for (int k = 0; k < 2; ++k) {
+    const int ir = k == 0 ? ir1 : ir2;
+    const bool ok = ir >= 1 && ir <= 4 * nside - 1;
+    HpRing r = hp_ring_info(nside, min(max(ir, 1), 4 * nside - 1));
+    const double dphi = 2.0 * M_PI / r.npix, sh = r.shifted ? 0.5 : 0.0;
+    const double tmp = phi / dphi - sh;
+    long long i1 = tmp < 0 ? (long long)tmp - 1 : (long long)tmp;
+    const double w1 = (phi - (i1 + sh) * dphi) / dphi;
+    long long i2 = i1 + 1;
+    if (i1 < 0) i1 += r.npix;
+    if (i2 >= r.npix) i2 -= r.npix;
+    if (ok) {
+      pix[2 * k] = r.start + i1;
+      pix[2 * k + 1] = r.start + i2;
+      wgt[2 * k] = 1.0 - w1;
+      wgt[2 * k + 1] = w1;
+    }
+    th[k] = r.theta;
+  }
+  if (ir1 == 0) {
+    const double wn = theta / th[1], fac = (1.0 - wn) * 0.25;
+    wgt[2] = wgt[2] * wn + fac;
+    wgt[3] = wgt[3] * wn + fac;
+    wgt[0] = wgt[1] = fac;
+    pix[0] = (pix[2] + 2) & 3;
+    pix[1] = (pix[3] + 2) & 3;
+  } else if (ir2 == 4 * nside) {
+    const double ws = (theta - th[0]) / (M_PI - th[0]), fac = ws * 0.25;
+    wgt[0] = wgt[0] * (1.0 - ws) + fac;
+    wgt[1] = wgt[1] * (1.0 - ws) + fac;
+    wgt[2] = wgt[3] = fac;
+    pix[2] = ((pix[0] + 2) & 3) + npix - 4;
+    pix[3] = ((pix[1] + 2) & 3) + npix - 4;
+  } else {
+    const double wt = (theta - th[0]) / (th[1] - th[0]);
+    wgt[0] *= 1.0 - wt;
+    wgt[1] *= 1.0 - wt;
+    wgt[2] *= wt;
+    wgt[3] *= wt;
+  }
+  for (int f = 0; f < nf; ++f) {
+    const double* m0 = maps + (size_t)f0[f] * npix;
+    const double* m1 = maps + (size_t)f1[f] * npix;
+    double v0 = 0.0, v1 = 0.0;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      v0 += wgt[k] * m0[pix[k]];
+      v1 += wgt[k] * m1[pix[k]];
+    }
+    out[f * npts + p] = (1.0 - wf[f]) * v0 + wf[f] * v1;
+  }
+}
+
 // ---------------------------------------------------------------- baseline products
 
 // R[b,f,t,s] = conj(V[f,t,i_b,s]) V[f,t,j_b,s].  A workgroup stages the voltages of all
@@ -538,6 +652,20 @@ int hydra_beam_bspline(const double* tx, int nx, const double* ty, int ny, const
   bspline2d_kernel<<<grid, 256, 0, as_stream(stream)>>>(tx, nx, ty, ny, coef, nf, x, y,
                                                         (size_t)npts, out);
   HYDRA_CHECK_LAUNCH("hydra_beam_bspline");
+  return HYDRA_OK;
+}
+
+int hydra_beam_healpix(const double* maps, int nmaps, int nside, const int32_t* f0,
+                       const int32_t* f1, const double* wf, int nf, const double* za,
+                       const double* az, long long npts, double* out, void* stream) {
+  HYDRA_CHECK_ARG(maps && f0 && f1 && wf && za && az && out,
+                  "hydra_beam_healpix: null pointer argument");
+  HYDRA_CHECK_ARG(nmaps > 0 && nside > 0 && nside <= 8192 && nf > 0 && npts > 0,
+                  "hydra_beam_healpix: bad sizes (nmaps=%d nside=%d nf=%d)", nmaps, nside, nf);
+  unsigned grid = (unsigned)((npts + 255) / 256);
+  beam_healpix_kernel<<<grid, 256, 0, as_stream(stream)>>>(maps, nside, f0, f1, wf, nf, za, az,
+                                                           (size_t)npts, out);
+  HYDRA_CHECK_LAUNCH("hydra_beam_healpix");
   return HYDRA_OK;
 }
 

@@ -71,6 +71,17 @@ int hydra_beam_bspline(const double* tx, int nx, const double* ty, int ny, const
                        int nf, const double* x, const double* y, long long npts, double* out,
                        void* stream);
 
+/* HEALPix-tabulated power beam (RING maps, one per tabulated channel): pyuvdata's
+ * "healpix_simple" interpolation -- bilinear over the four nearest pixels at (theta = za,
+ * phi = az) -- with linear interpolation between channels, as the reference's SH response
+ * script configures its UVBeam (scripts/precompute_response_sh_singlefreq_general.py:106-110;
+ * consumed at vis_simulator.py:340-349):
+ *   out[f,p] = (1 - wf[f]) I(maps[f0[f]], p) + wf[f] I(maps[f1[f]], p),  I = 4-pixel sum.
+ * maps (nmaps, 12 nside^2); f0, f1 (nf) int32 map indices and wf (nf) from the host.        */
+int hydra_beam_healpix(const double* maps, int nmaps, int nside, const int32_t* f0,
+                       const int32_t* f1, const double* wf, int nf, const double* za,
+                       const double* az, long long npts, double* out, void* stream);
+
 /* ---- response generator ---------------------------------------------------------- */
 
 /* Antenna voltages V (Nf,Nt,Nant,Ns) c128:

@@ -180,3 +180,38 @@ class SplineBeam:
         out = [RectBivariateSpline(self.za_grid, self.az_grid, self.grid_at(f), kx=3, ky=3)
                .ev(za, az) for f in np.atleast_1d(freq_array)]
         return np.asarray(out)[np.newaxis, np.newaxis, :, :]
+
+
+class HealpixBeam:
+    """Power beam tabulated on a HEALPix map (RING) per frequency -- a pyuvdata ``UVBeam`` in
+    healpix coordinates with ``interpolation_function = "healpix_simple"`` and
+    ``freq_interp_kind = "linear"``, as the reference's SH response script sets it up
+    (scripts/precompute_response_sh_singlefreq_general.py:106-110): bilinear interpolation over
+    the four nearest pixels (theta = za, phi = az) and linear interpolation between channels.
+    Parity unpinned: the arithmetic is pyuvdata's / astropy-healpix's, restated from the HEALPix
+    bilinear scheme (oracle.sphere.interp_weights_ring)."""
+
+    beam_type = "power"
+    Npols = 1
+    polarization_array = np.array([-5])
+
+    def __init__(self, freqs_hz, power):
+        self.freqs = np.atleast_1d(np.asarray(freqs_hz, dtype=np.float64))
+        self.power = np.atleast_2d(np.asarray(power, dtype=np.float64))
+        assert self.power.shape[0] == self.freqs.size
+        self.nside = int(round(np.sqrt(self.power.shape[1] / 12.0)))
+        assert 12 * self.nside ** 2 == self.power.shape[1]
+
+    def compute_response(self, *, az_array, za_array, freq_array, **_unused):
+        from . import sphere
+        from scipy.interpolate import interp1d
+        az = np.asarray(az_array, dtype=np.float64)
+        za = np.asarray(za_array, dtype=np.float64)
+        pix, wgt = sphere.interp_weights_ring(self.nside, za.ravel(), az.ravel())
+        freq = np.atleast_1d(np.asarray(freq_array, dtype=np.float64))
+        if self.freqs.size == 1:
+            maps = np.repeat(self.power, freq.size, axis=0)
+        else:
+            maps = interp1d(self.freqs, self.power, kind="linear", axis=0)(freq)
+        vals = np.sum(maps[:, pix] * wgt[None], axis=1)          # (Nfreq, Npts)
+        return vals.reshape((1, 1, freq.size) + az.shape)

@@ -168,3 +168,88 @@ def unit_mode_maps(lmax, nside):
             maps[n] = 2.0 * lam[n] * np.cos(m * phi)
             maps[n + nalm] = -2.0 * lam[n] * np.sin(m * phi)
     return maps
+
+
+def _ring_info(nside, ring):
+    """(startpix, ringpix, theta, shifted) of RING-scheme iso-latitude ring 1 .. 4 nside - 1
+    (HEALPix get_ring_info2)."""
+    nside = int(nside)
+    ring = np.asarray(ring, dtype=np.int64)
+    npix = 12 * nside * nside
+    ncap = 2 * nside * (nside - 1)
+    fact2 = 4.0 / npix
+    fact1 = (2 * nside) * fact2
+    north = np.where(ring > 2 * nside, 4 * nside - ring, ring)
+    capr = north < nside
+    tmp = north * north * fact2
+    costh = np.where(capr, 1.0 - tmp, (2 * nside - north) * fact1)
+    sinth = np.sqrt(np.maximum((1.0 - costh) * (1.0 + costh), 0.0))
+    theta = np.where(capr, np.arctan2(sinth, costh), np.arccos(np.clip(costh, -1.0, 1.0)))
+    ringpix = np.where(capr, 4 * north, 4 * nside)
+    shifted = np.where(capr, True, ((north - nside) & 1) == 0)
+    startpix = np.where(capr, 2 * north * (north - 1), ncap + (north - nside) * 4 * nside)
+    south = north != ring
+    theta = np.where(south, np.pi - theta, theta)
+    startpix = np.where(south, npix - startpix - ringpix, startpix)
+    return startpix, ringpix, theta, shifted
+
+
+def interp_weights_ring(nside, theta, phi):
+    """The four RING-scheme pixels and weights of HEALPix's bilinear interpolation at
+    (theta, phi) (Healpix_Base::get_interpol -- what healpy.get_interp_weights and
+    astropy-healpix's bilinear_interpolation_weights return, hence pyuvdata's
+    ``healpix_simple`` beam interpolation).  Returns (pix (4, N) int64, wgt (4, N))."""
+    nside = int(nside)
+    theta = np.atleast_1d(np.asarray(theta, dtype=np.float64))
+    phi = np.mod(np.atleast_1d(np.asarray(phi, dtype=np.float64)), 2.0 * np.pi)
+    npix = 12 * nside * nside
+    z = np.cos(theta)
+    az = np.abs(z)
+    ir_eq = (nside * (2.0 - 1.5 * z)).astype(np.int64)
+    ir_cap = (nside * np.sqrt(3.0 * (1.0 - az))).astype(np.int64)
+    ir1 = np.where(az <= 2.0 / 3.0, ir_eq, np.where(z > 0, ir_cap, 4 * nside - ir_cap - 1))
+    ir2 = ir1 + 1
+    pix = np.zeros((4, theta.size), dtype=np.int64)
+    wgt = np.zeros((4, theta.size), dtype=np.float64)
+    th = [np.zeros(theta.size), np.zeros(theta.size)]
+    for k, ir in enumerate((ir1, ir2)):
+        ok = (ir >= 1) & (ir <= 4 * nside - 1)
+        sp, nr, thr, shift = _ring_info(nside, np.clip(ir, 1, 4 * nside - 1))
+        dphi = 2.0 * np.pi / nr
+        tmp = phi / dphi - 0.5 * shift
+        i1 = np.where(tmp < 0, tmp.astype(np.int64) - 1, tmp.astype(np.int64))
+        w1 = (phi - (i1 + 0.5 * shift) * dphi) / dphi
+        i2 = i1 + 1
+        i1 = np.where(i1 < 0, i1 + nr, i1)
+        i2 = np.where(i2 >= nr, i2 - nr, i2)
+        pix[2 * k] = np.where(ok, sp + i1, 0)
+        pix[2 * k + 1] = np.where(ok, sp + i2, 0)
+        wgt[2 * k] = np.where(ok, 1.0 - w1, 0.0)
+        wgt[2 * k + 1] = np.where(ok, w1, 0.0)
+        th[k] = thr
+    npole, spole = ir1 == 0, ir2 == 4 * nside
+    mid = ~(npole | spole)
+    wt = np.where(mid, (theta - th[0]) / np.where(mid, th[1] - th[0], 1.0), 0.0)
+    wgt[0] = np.where(mid, wgt[0] * (1.0 - wt), wgt[0])
+    wgt[1] = np.where(mid, wgt[1] * (1.0 - wt), wgt[1])
+    wgt[2] = np.where(mid, wgt[2] * wt, wgt[2])
+    wgt[3] = np.where(mid, wgt[3] * wt, wgt[3])
+    # north polar cap: the four pixels of ring 1 stand in for the missing ring
+    wn = theta / th[1]
+    fac = (1.0 - wn) * 0.25
+    wgt[2] = np.where(npole, wgt[2] * wn + fac, wgt[2])
+    wgt[3] = np.where(npole, wgt[3] * wn + fac, wgt[3])
+    wgt[0] = np.where(npole, fac, wgt[0])
+    wgt[1] = np.where(npole, fac, wgt[1])
+    pix[0] = np.where(npole, (pix[2] + 2) & 3, pix[0])
+    pix[1] = np.where(npole, (pix[3] + 2) & 3, pix[1])
+    # south polar cap
+    ws = (theta - th[0]) / (np.pi - th[0])
+    fac = ws * 0.25
+    wgt[0] = np.where(spole, wgt[0] * (1.0 - ws) + fac, wgt[0])
+    wgt[1] = np.where(spole, wgt[1] * (1.0 - ws) + fac, wgt[1])
+    wgt[2] = np.where(spole, fac, wgt[2])
+    wgt[3] = np.where(spole, fac, wgt[3])
+    pix[2] = np.where(spole, ((pix[0] + 2) & 3) + npix - 4, pix[2])
+    pix[3] = np.where(spole, ((pix[1] + 2) & 3) + npix - 4, pix[3])
+    return pix, wgt

@@ -723,6 +723,56 @@ def test_simulator_with_gridded_beams_matches_oracle(hy, orc):
         assert operr(got, ref) < OP_TOL
 
 
+def _healpix_beam_pair(hy, orc, nside=16, nfreq=3):
+    th, ph = orc.sphere.pix2ang_ring(nside, np.arange(12 * nside * nside))
+    freqs = np.linspace(95e6, 125e6, nfreq)
+    nu = (freqs - 100e6) / 20e6
+    rng = np.random.RandomState(8)
+    maps = (np.exp(-(th[None, :] / (0.3 + 0.05 * nu[:, None])) ** 2)
+            * (1.0 + 0.2 * np.cos(2 * ph[None, :]) * np.sin(th[None, :]) ** 2)
+            + 0.02 + 1e-4 * rng.rand(nfreq, th.size))
+    return hy.beams.HealpixBeam(freqs, maps), orc.beams.HealpixBeam(freqs, maps)
+
+
+def test_healpix_beam_device_interpolation_matches_oracle(hy, orc):
+    """hydra_beam_healpix (pyuvdata "healpix_simple": four-pixel bilinear weights, linear in
+    frequency) against the oracle's restatement at random directions, pixel centres, both poles,
+    ring boundaries and phi = 0 / 2 pi; several resolutions."""
+    rng = np.random.RandomState(12)
+    for nside in (1, 2, 16, 64):
+        bh, bo = _healpix_beam_pair(hy, orc, nside=nside)
+        tc, pc = orc.sphere.pix2ang_ring(nside, np.arange(min(12 * nside * nside, 500)))
+        zq = np.concatenate([np.arccos(rng.uniform(-1, 1, 4000)), tc, tc + 1e-12, tc - 1e-12,
+                             [0.0, np.pi, 1e-9, np.pi - 1e-9, 0.7, 0.7, 0.7]])
+        aq = np.concatenate([rng.uniform(-np.pi, 3 * np.pi, 4000), pc, pc, pc,
+                             [0.3, 1.0, 2.0, 4.0, 0.0, 2 * np.pi, 2 * np.pi - 1e-14]])
+        fq = np.array([95e6, 101.7e6, 110e6, 125e6])
+        got = bh.compute_response(az_array=aq, za_array=zq, freq_array=fq)
+        want = bo.compute_response(az_array=aq, za_array=zq, freq_array=fq)
+        assert got.shape == want.shape == (1, 1, fq.size, zq.size)
+        assert operr(got, want) < 1e-12
+    with pytest.raises(ValueError):
+        bh.compute_response(az_array=aq[:3], za_array=zq[:3], freq_array=[90e6])
+
+
+def test_simulator_with_healpix_beams_matches_oracle(hy, orc):
+    """Per-source response with HEALPix-tabulated beams (shared, and mixed with analytic ones)."""
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup((3, 4), 60, 3, 4, seed=9, wide=True)
+    nant = len(ant_pos)
+    bh, bo = _healpix_beam_pair(hy, orc)
+    for mixed in (False, True):
+        beams_h = [bh] * nant
+        beams_o = [bo] * nant
+        if mixed:
+            beams_h = [bh if a % 2 else hy.beams.GaussianBeam(diameter=14.0) for a in range(nant)]
+            beams_o = [bo if a % 2 else orc.beams.GaussianBeam(diameter=14.0) for a in range(nant)]
+        ref = orc.response.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6, times,
+                                                   beams_o, latitude=LAT)
+        got = hy.vis_simulator.simulate_vis_per_source(ant_pos, fluxes, ra, dec, freqs * 1e6,
+                                                       times, beams_h, latitude=LAT)
+        assert operr(got, ref) < OP_TOL
+
+
 def test_large_array_factored_operator_matches_oracle(hy, orc):
     """170 antennas: all antennas x 64 sources no longer fit in LDS, so R x and R^H z use the
     16-source staging; the Gram walks 9 x 9 antenna-block segments.  Factored system vs oracle."""

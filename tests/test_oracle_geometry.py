@@ -277,3 +277,53 @@ def test_spline_beam_reproduces_a_smooth_beam_and_wraps_in_azimuth():
     hi = bm.compute_response(az_array=np.array([2 * np.pi - 1e-9]), za_array=np.array([0.4]),
                              freq_array=fq)
     assert np.max(np.abs(lo - hi)) < 1e-8
+
+
+def test_healpix_bilinear_weights_known_answers():
+    """oracle.sphere.interp_weights_ring (the HEALPix bilinear scheme behind pyuvdata's
+    "healpix_simple"): weights are a partition of unity, reproduce a map exactly at pixel centres
+    (all resolutions, caps and equatorial belt), are continuous across ring boundaries, treat the
+    poles symmetrically, and converge to a smooth field as the pixels shrink."""
+    from oracle import sphere
+    rng = np.random.RandomState(1)
+    for nside in (1, 2, 4, 8):
+        npix = 12 * nside * nside
+        th, ph = sphere.pix2ang_ring(nside, np.arange(npix))
+        pix, w = sphere.interp_weights_ring(nside, th, ph)
+        assert np.allclose(w.sum(0), 1.0, atol=1e-14)
+        m = rng.randn(npix)
+        assert np.max(np.abs((m[pix] * w).sum(0) - m)) < 1e-13
+    th = np.arccos(rng.uniform(-1, 1, 20000))
+    ph = rng.uniform(0, 2 * np.pi, 20000)
+    errs = []
+    for nside in (8, 16, 32):
+        pix, w = sphere.interp_weights_ring(nside, th, ph)
+        assert np.allclose(w.sum(0), 1.0, atol=1e-13) and w.min() > -1e-12
+        assert pix.min() >= 0 and pix.max() < 12 * nside * nside
+        tp, pp = sphere.pix2ang_ring(nside, np.arange(12 * nside * nside))
+        f = lambda t, p: np.cos(t) + 0.3 * np.sin(t) * np.cos(p - 0.4)        # noqa: E731
+        errs.append(np.max(np.abs((f(tp, pp)[pix] * w).sum(0) - f(th, ph))))
+    assert errs[1] < 0.6 * errs[0] and errs[2] < 0.6 * errs[1] and errs[2] < 3e-3   # converges
+    # exactly at a pole: the mean of the four cap pixels; phi wraps at 2 pi
+    m = rng.randn(12 * 16)
+    pix, w = sphere.interp_weights_ring(4, [0.0, np.pi], [0.3, 1.0])
+    assert np.allclose((m[pix] * w).sum(0), [m[:4].mean(), m[-4:].mean()])
+    pa, wa = sphere.interp_weights_ring(4, [1.0, 1.0], [1e-13, 2 * np.pi - 1e-13])
+    assert abs((m[pa] * wa).sum(0)[0] - (m[pa] * wa).sum(0)[1]) < 1e-10
+    # continuity across a ring: just above / below a pixel centre's latitude
+    t0, p0 = sphere.pix2ang_ring(8, np.array([200]))
+    va = [(m2 := np.arange(768.0) ** 0.5)[px] @ wx for px, wx in
+          [tuple(a[:, 0] for a in sphere.interp_weights_ring(8, t0 + d, p0)) for d in (-1e-9, 1e-9)]]
+    assert abs(va[0] - va[1]) < 1e-6
+
+
+def test_healpix_beam_oracle_interpolates_linearly_in_frequency():
+    from oracle import beams, sphere
+    nside = 4
+    th, ph = sphere.pix2ang_ring(nside, np.arange(12 * nside * nside))
+    maps = np.stack([np.cos(th) ** 2, 2.0 * np.cos(th) ** 2 + 1.0])
+    hb = beams.HealpixBeam([100e6, 120e6], maps)
+    out = hb.compute_response(az_array=ph[:7], za_array=th[:7], freq_array=[100e6, 105e6, 120e6])
+    assert out.shape == (1, 1, 3, 7)
+    assert np.allclose(out[0, 0, 0], maps[0, :7]) and np.allclose(out[0, 0, 2], maps[1, :7])
+    assert np.allclose(out[0, 0, 1], 0.75 * maps[0, :7] + 0.25 * maps[1, :7])
