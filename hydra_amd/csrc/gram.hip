@@ -760,13 +760,14 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
     sc = min(sc, ns - 1);
     off[i] = (unsigned)(r * ns + sc) * 16u;
   }
-  auto issue = [&](int p) {
+  // pieces i0 .. i1-1 of phase p (this wave's share)
+  auto issue = [&](int p, int i0, int i1) {
     int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
     const char* src = reinterpret_cast<const char*>(U + ((size_t)ft * nantp + c * UCH) * ns);   // uniform
     f64x2* dst = s_u + (size_t)buf * UCH * K3_W + wave * 64;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
-      if (wave + 2 * K3_WC * i < K3_PIECES) {
+      if (i >= i0 && i < i1 && wave + 2 * K3_WC * i < K3_PIECES) {
         __builtin_amdgcn_global_load_lds(
             (const __attribute__((address_space(1))) void*)(src + off[i]),
             (__attribute__((address_space(3))) void*)(dst + 2 * K3_WC * 64 * i), 16, 0, 0);
@@ -780,14 +781,31 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
 #pragma unroll
     for (int j = 0; j < 2; ++j) G[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  if (nphase > 0) issue(0);
+  if (nphase > 0) issue(0, 0, NPW);
   const int offA = wr * 48 + lc;
   const int offB = K3_TR + wc * 32 + lc;
+#ifdef HYDRA_GRAM_STAMPS
+  unsigned long long u0, u1, u2, u3, u4, s_bar = 0, s_dma = 0, s_ks = 0, s_ep = 0;
+  unsigned long long k_c0 = __builtin_amdgcn_s_memtime();
+#endif
   for (int p = 0; p < nphase; ++p) {
     int c = p % nc, buf = p & 1;
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(u0)
+#endif
     __syncthreads();  // phase p has landed (vmcnt drained before the barrier); the other buffer
                       // is no longer being read
-    if (p + 1 < nphase) issue(p + 1);
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(u1)
+#endif
+    // (the next phase's staging is issued piece by piece between the matrix instructions of
+    // the first k-step: issued in one go after the barrier, the nine LDS-DMA instructions of a
+    // wave -- and of its SIMD sibling at the same time -- kept the matrix pipe idle for ~800
+    // cycles per phase, 5 % of the kernel)
+    const bool stage_next = p + 1 < nphase;
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(u2)
+#endif
     int ksteps = min(UCH, nantp - c * UCH) >> 2;
     const f64x2* ub = s_u + (size_t)(buf * UCH + kr) * K3_W;
     if (c == 0) {
@@ -842,6 +860,13 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
           P1[rb][cb] = mfma(a[rb].x, b[cb].x, P1[rb][cb]);
           P2[rb][cb] = mfma(a[rb].y, b[cb].y, P2[rb][cb]);
           P3[rb][cb] = mfma(as[rb], bd, P3[rb][cb]);
+          if (kk == 0 && stage_next) {
+            constexpr int PER = (NPW + 5) / 6;     // pieces per group of three MFMAs
+            const int grp = cb * 3 + rb;
+            __builtin_amdgcn_sched_barrier(0);
+            issue(p + 1, grp * PER, grp * PER + PER);
+            __builtin_amdgcn_sched_barrier(0);
+          }
         }
         if (!SAMEBEAM) {
           const double bq = b[cb].x * b[cb].x + b[cb].y * b[cb].y;
@@ -859,6 +884,9 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
 #pragma unroll
     for (int kk = 0; kk < UCH / 4; ++kk)
       if (kk < ksteps) kstep(kk);
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(u3)
+#endif
     if (c == nc - 1) {
 #pragma unroll
       for (int i = 0; i < 3; ++i)
@@ -871,7 +899,17 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
             G[i][j][g] = fma(tim, tim, fma(tre, tre, G[i][j][g]));
           }
     }
+#ifdef HYDRA_GRAM_STAMPS
+    STAMP(u4)
+    s_bar += u1 - u0; s_dma += u2 - u1; s_ks += u3 - u2; s_ep += u4 - u3;
+#endif
   }
+#ifdef HYDRA_GRAM_STAMPS
+  if (blockIdx.x == 0 && threadIdx.x == 0) {
+    g_stamps[0] += s_bar; g_stamps[1] += s_dma; g_stamps[2] += s_ks; g_stamps[3] += s_ep;
+    g_stamps[4] += nphase; g_stamps[5] += __builtin_amdgcn_s_memtime() - k_c0;
+  }
+#endif
   double* slab = slabs + ((size_t)split * ntiles + tile) * K3_TILE;
 #pragma unroll
   for (int rb = 0; rb < 3; ++rb)
