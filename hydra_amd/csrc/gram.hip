@@ -760,17 +760,25 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
     sc = min(sc, ns - 1);
     off[i] = (unsigned)(r * ns + sc) * 16u;
   }
-  // pieces i0 .. i1-1 of phase p (this wave's share)
+  // Pieces i0 .. i1-1 of phase p (this wave's share).  The LDS-DMA instruction is written out by
+  // hand: issued through the compiler's builtin, a FLAT-encoded operation that touches LDS puts
+  // the compiler's wait-count bookkeeping into a mode where EVERY later wait in the wave is for
+  // vmcnt(0) / lgkmcnt(0) as long as the DMA may be in flight -- here the whole phase -- so no
+  // LDS read could stay in flight across a matrix instruction.  What the compiler does not see it
+  // does not wait for; the one wait the DMA needs (all of it landed before the barrier) is
+  // explicit below.
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_u + wave * 64));
   auto issue = [&](int p, int i0, int i1) {
     int ft = ft_begin + p / nc, c = p % nc, buf = p & 1;
     const char* src = reinterpret_cast<const char*>(U + ((size_t)ft * nantp + c * UCH) * ns);   // uniform
-    f64x2* dst = s_u + (size_t)buf * UCH * K3_W + wave * 64;
+    const unsigned dst = lds_wave + (unsigned)(buf * UCH * K3_W) * 16u;
 #pragma unroll
     for (int i = 0; i < NPW; ++i) {
       if (i >= i0 && i < i1 && wave + 2 * K3_WC * i < K3_PIECES) {
-        __builtin_amdgcn_global_load_lds(
-            (const __attribute__((address_space(1))) void*)(src + off[i]),
-            (__attribute__((address_space(3))) void*)(dst + 2 * K3_WC * 64 * i), 16, 0, 0);
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst + (unsigned)(2 * K3_WC * 64 * i) * 16u), "v"(off[i]), "s"(src)
+                     : "memory");
       }
     }
   };
@@ -793,8 +801,8 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
 #ifdef HYDRA_GRAM_STAMPS
     STAMP(u0)
 #endif
-    __syncthreads();  // phase p has landed (vmcnt drained before the barrier); the other buffer
-                      // is no longer being read
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of phase p have landed
+    __syncthreads();  // everyone's have; the other buffer is no longer being read
 #ifdef HYDRA_GRAM_STAMPS
     STAMP(u1)
 #endif
@@ -818,72 +826,78 @@ gram_uniform_kernel(const f64x2* __restrict__ U, int nft, int nantp, int ns, int
           P3[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
         }
     }
-    // One k-step (4 antennas).  All five operand reads go out first and are waited for once: with
-    // the B operands read between the two column bursts a k-step had three exposed LDS round
-    // trips, and the two waves of a SIMD, running the same instruction stream in step, spent them
-    // idle together.  Only in the k-step that holds the q row (SAMEBEAM) the q lane is masked out
-    // of the products and the rank-one term applied; every other k-step uses the operands as read
-    // (the masks used to run in all of them: 20 VALU ops and 18 registers).
-    auto kstep = [&](int kk) {
+    // K-steps of 4 antennas.  The operands of k-step kk+1 are read INTO THE REGISTERS OF kk as
+    // those fall free, in the order of their use: the first column block's B after the first
+    // burst of nine matrix instructions, each row block's A after its last use in the second
+    // burst, the second column block's B at the end -- every read is at least six matrix
+    // instructions (384 cycles) ahead of its first use, no register is added, and the waits the
+    // compiler places are counted (lgkmcnt(n)), not drains.  Before, a k-step began with LDS round
+    // trips (three at first, then one) that left the matrix pipe idle: the SIMD's other wave,
+    // which arbitration lets run only in those gaps, met the same gaps later with nobody to fill
+    // them.  Only in the k-step that holds the q row (SAMEBEAM) the q lane is masked out of the
+    // products and the rank-one term applied; every other k-step uses the operands as read (the
+    // masks used to run in all of them: 20 VALU ops and 18 registers).
+    auto ld = [&](int kk, int which) -> f64x2 {      // which: 0..2 = A row block, 3..4 = B column block
       const f64x2* up = ub + kk * 4 * K3_W;
-      const bool qstep = SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3));   // uniform
-      f64x2 a[3], b[2];
+      return which < 3 ? up[offA + which * 16] : up[offB + (which - 3) * 16];
+    };
+    auto m3 = [&](const f64x2& av, const f64x2& bv, int rb, int cb) {
+      P1[rb][cb] = mfma(av.x, bv.x, P1[rb][cb]);
+      P2[rb][cb] = mfma(av.y, bv.y, P2[rb][cb]);
+      P3[rb][cb] = mfma(av.x + av.y, bv.x - bv.y, P3[rb][cb]);
+      if (!SAMEBEAM)
+        G[rb][cb] = mfma(-(av.x * av.x + av.y * av.y), bv.x * bv.x + bv.y * bv.y, G[rb][cb]);
+    };
+    f64x2 a0, a1, a2, b0, b1;
+    if (ksteps > 0) {
+      b0 = ld(0, 3); a0 = ld(0, 0); a1 = ld(0, 1); a2 = ld(0, 2); b1 = ld(0, 4);   // (steady-state order)
+    }
 #pragma unroll
-      for (int rb = 0; rb < 3; ++rb) a[rb] = up[offA + rb * 16];
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) b[cb] = up[offB + cb * 16];
-      double nq[3] = {0.0, 0.0, 0.0};
-      if (SAMEBEAM) {
-        if (qstep) {
-          // a real branch (the empty asm keeps it from being turned into selects): it touches
-          // operand registers only, never an accumulator
+    for (int kk = 0; kk < UCH / 4; ++kk) {
+      if (kk < ksteps) {
+        const int kn = min(kk + 1, ksteps - 1);      // (the last k-step re-reads itself: no branch)
+        if (SAMEBEAM && (c * UCH + kk * 4 == (qrow & ~3))) {
+          // a real branch (the empty asm keeps it from being turned into selects)
           asm volatile("" ::: "memory");
           const bool qlane = kr == (qrow & 3);
+          f64x2* av[3] = {&a0, &a1, &a2};
 #pragma unroll
           for (int rb = 0; rb < 3; ++rb) {
-            nq[rb] = qlane ? -a[rb].x : 0.0;
-            if (qlane) a[rb] = f64x2{0.0, 0.0};
+            const double nqv = qlane ? -av[rb]->x : 0.0;
+            G[rb][0] = mfma(nqv, b0.x, G[rb][0]);
+            G[rb][1] = mfma(nqv, b1.x, G[rb][1]);
+            if (qlane) *av[rb] = f64x2{0.0, 0.0};
           }
         }
-      } else {
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) nq[rb] = -(a[rb].x * a[rb].x + a[rb].y * a[rb].y);
+        __builtin_amdgcn_sched_barrier(0);
+        m3(a0, b0, 0, 0);
+        if (kk == 0 && stage_next) issue(p + 1, 0, 2);
+        __builtin_amdgcn_sched_barrier(0);   // (else the three a.x + a.y are hoisted to the top,
+        m3(a1, b0, 1, 0);                    //  and with them the waits for all three reads)
+        if (kk == 0 && stage_next) issue(p + 1, 2, 4);
+        __builtin_amdgcn_sched_barrier(0);
+        m3(a2, b0, 2, 0);
+        if (kk == 0 && stage_next) issue(p + 1, 4, 6);
+        __builtin_amdgcn_sched_barrier(0);
+        b0 = ld(kn, 3);
+        __builtin_amdgcn_sched_barrier(0);
+        m3(a0, b1, 0, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        a0 = ld(kn, 0);
+        if (kk == 0 && stage_next) issue(p + 1, 6, 8);
+        __builtin_amdgcn_sched_barrier(0);
+        m3(a1, b1, 1, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        a1 = ld(kn, 1);
+        if (kk == 0 && stage_next) issue(p + 1, 8, NPW);
+        __builtin_amdgcn_sched_barrier(0);
+        m3(a2, b1, 2, 1);
+        __builtin_amdgcn_sched_barrier(0);
+        a2 = ld(kn, 2);
+        b1 = ld(kn, 4);
+        __builtin_amdgcn_sched_barrier(0);
       }
-      double as[3];
-#pragma unroll
-      for (int rb = 0; rb < 3; ++rb) as[rb] = a[rb].x + a[rb].y;
-#pragma unroll
-      for (int cb = 0; cb < 2; ++cb) {
-        const double bd = b[cb].x - b[cb].y;
-#pragma unroll
-        for (int rb = 0; rb < 3; ++rb) {
-          P1[rb][cb] = mfma(a[rb].x, b[cb].x, P1[rb][cb]);
-          P2[rb][cb] = mfma(a[rb].y, b[cb].y, P2[rb][cb]);
-          P3[rb][cb] = mfma(as[rb], bd, P3[rb][cb]);
-          if (kk == 0 && stage_next) {
-            constexpr int PER = (NPW + 5) / 6;     // pieces per group of three MFMAs
-            const int grp = cb * 3 + rb;
-            __builtin_amdgcn_sched_barrier(0);
-            issue(p + 1, grp * PER, grp * PER + PER);
-            __builtin_amdgcn_sched_barrier(0);
-          }
-        }
-        if (!SAMEBEAM) {
-          const double bq = b[cb].x * b[cb].x + b[cb].y * b[cb].y;
-#pragma unroll
-          for (int rb = 0; rb < 3; ++rb) G[rb][cb] = mfma(nq[rb], bq, G[rb][cb]);
-        }
-      }
-      if (SAMEBEAM && qstep) {
-#pragma unroll
-        for (int cb = 0; cb < 2; ++cb)
-#pragma unroll
-          for (int rb = 0; rb < 3; ++rb) G[rb][cb] = mfma(nq[rb], b[cb].x, G[rb][cb]);
-      }
-    };
-#pragma unroll
-    for (int kk = 0; kk < UCH / 4; ++kk)
-      if (kk < ksteps) kstep(kk);
+    }
 #ifdef HYDRA_GRAM_STAMPS
     STAMP(u3)
 #endif
