@@ -377,17 +377,22 @@ chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
     const int gr = min(row0 + pr, n - 1) - row0;
     off[i] = (unsigned)gr * (unsigned)n * 8u + (unsigned)c * 16u;
   }
-  auto issue = [&](int kc, int buf) {
-    unsigned char* dst = smem + buf * STG_BYTES + wave * 1024;
+  // (LDS-DMA by hand-written asm: through the compiler's builtin every later wait in the wave
+  // becomes lgkmcnt(0) / vmcnt(0) while a DMA may be in flight -- see gram_uniform_kernel)
+  const unsigned lds_wave = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)(smem + wave * 1024));
+  auto issue = [&](int kc, int buf, int i0, int i1) {
+    const unsigned dst = lds_wave + (unsigned)(buf * STG_BYTES);
 #pragma unroll
     for (int i = 0; i < 8; ++i) {
-      const char* src = ((i < 4) ? baseA : baseB) + off[i] + kc * (KC * 8);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dst + i * 4096),
-                                       16, 0, 0);
+      if (i >= i0 && i < i1) {
+        const char* src = ((i < 4) ? baseA : baseB) + kc * (KC * 8);     // uniform
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst + (unsigned)(i * 4096)), "v"(off[i]), "s"(src) : "memory");
+      }
     }
   };
-  issue(0, 0);
+  issue(0, 0, 0, 8);
 
   // accumulators start as -C (negation is exact; the sum of products is added, -acc stored)
   f64x4 acc[4][4];
@@ -411,9 +416,12 @@ chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
     const int buf = kc & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk kc have landed
     __syncthreads();                                   // ... everyone's; stage buf^1 is free again
-    if (kc + 1 < NKC) issue(kc + 1, buf ^ 1);
+    const bool more = kc + 1 < NKC;
     const unsigned char* sa = rdA + buf * STG_BYTES;
     const unsigned char* sb = rdB + buf * STG_BYTES;
+    // Reads in the order of use (first half of the chunk's k-values, then the second: the second
+    // half arrives under the first 32 matrix instructions, the compiler's waits are counted);
+    // the next chunk's staging goes out two pieces at a time between the bursts.
     f64x2 a0[4], a1[4], b0[4], b1[4];
 #pragma unroll
     for (int m = 0; m < 4; ++m) {
@@ -425,14 +433,21 @@ chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
       a1[m] = *reinterpret_cast<const f64x2*>(sa + m * 16 * KC * 8 + p1);
       b1[m] = *reinterpret_cast<const f64x2*>(sb + m * 16 * KC * 8 + p1);
     }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma64(a0[mi].x, b0[ni].x, acc[mi][ni]);
+      if (more) issue(kc + 1, buf ^ 1, mi, mi + 1);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-    for (int mi = 0; mi < 4; ++mi)
+    for (int mi = 0; mi < 4; ++mi) {
 #pragma unroll
       for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma64(a0[mi].y, b0[ni].y, acc[mi][ni]);
+      if (more) issue(kc + 1, buf ^ 1, 4 + mi, 5 + mi);
+    }
+    __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
