@@ -90,53 +90,6 @@ struct Frag {
   double are[4], aim[4], bre[4], bim[4];
 };
 
-template <bool EDGE>
-struct RowsProducer {
-  const f64x2* __restrict__ R;
-  const f64x2* __restrict__ rows;
-  long long k_end;
-  int ns;
-  int ca[4], cb[4];
-  double ma[4], mb[4];
-  int kr;
-  f64x2 c;
-
-  __device__ __forceinline__ void init(const f64x2* R_, const f64x2* rows_, long long k_end_,
-                                       int ns_, int colA, int colB, int lane) {
-    R = R_; rows = rows_; k_end = k_end_; ns = ns_; kr = lane >> 4;
-#pragma unroll
-    for (int i = 0; i < 4; ++i) {
-      int a = colA + i * 16, b = colB + i * 16;
-      ma[i] = (!EDGE || a < ns) ? 1.0 : 0.0;
-      mb[i] = (!EDGE || b < ns) ? 1.0 : 0.0;
-      ca[i] = EDGE ? min(a, ns - 1) : a;
-      cb[i] = EDGE ? min(b, ns - 1) : b;
-    }
-  }
-  f64x2 xa[4], xb[4];
-  // loads of the k-step starting at k0 (row clamped and zero-weighted past the end)
-  __device__ __forceinline__ void issue(long long k0) {
-    long long row = k0 + kr;
-    bool valid = row < k_end;
-    if (!valid) row = k_end - 1;
-    c = f64x2{1.0, 0.0};
-    if (rows) c = rows[row];
-    if (!valid) c = f64x2{0.0, 0.0};
-    const f64x2* rp = R + (size_t)row * ns;
-#pragma unroll
-    for (int g = 0; g < 4; ++g) { xa[g] = rp[ca[g]]; xb[g] = rp[cb[g]]; }
-  }
-  __device__ __forceinline__ void finish(Frag& f) const {
-#pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      f64x2 y = cmul(c, xa[g]);
-      f64x2 z = cmul(c, xb[g]);
-      if (EDGE) { y.x *= ma[g]; y.y *= ma[g]; z.x *= mb[g]; z.y *= mb[g]; }
-      f.are[g] = y.x; f.aim[g] = y.y; f.bre[g] = z.x; f.bim[g] = z.y;
-    }
-  }
-};
-
 // Software pipeline of one wave.  FP64 VALU work does not hide under an f64 MFMA on gfx950
 // (both run on the SIMD's FP64 lanes: tools/mfma_peak.hip measures +18 cycles for the first
 // v_fma_f64 placed after an MFMA and ~4.5 for each further one), and with one wave per SIMD a
@@ -187,28 +140,36 @@ __device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long l
 #endif
 }
 
-template <bool EDGE>
-__device__ __forceinline__ void gram_rows_loop(const f64x2* __restrict__ R,
-                                               const f64x2* __restrict__ rows, long long k_begin,
-                                               long long k_end, int ns, int colA, int colB,
-                                               int lane, f64x4 (&acc)[4][4]) {
-  RowsProducer<EDGE> prod;
-  prod.init(R, rows, k_end, ns, colA, colB, lane);
-  mfma_pipeline(prod, k_begin, k_end, acc);
-}
+// Gram of a materialised operator: G = Re((c R)^H (c R)) = sum_rows |c_row|^2 Re(conj(R_row,i) R_row,j),
+// a real rank-2M update.  128 x 128 output tile per 4-wave workgroup (wave tile 64 x 64), two
+// workgroups per CU; the rows are walked in chunks of 8: both operand strips (8 rows x 128 columns
+// x 16 B) and the chunk's row factors are copied by LDS-DMA into one of two LDS stages one chunk
+// ahead, so that the four waves share every fetched byte (the first version let every wave load
+// its own operands from global memory, 8 loads per lane and k-step: 47-52 % of the matrix peak).
+// Lane (i = l & 15, g = l >> 4) of an MFMA needs X[k = 4 step + g][column i]: the complex element
+// (row 4 s + g, column i) read with ONE ds_read_b128 feeds two steps, k = (row, re) and (row, im).
+// 16 lanes read 256 contiguous bytes (all banks once), the four row groups are separate passes:
+// no conflict, no swizzle.  Only |c|^2 survives in the product, so it multiplies the A operands
+// alone.  Rows past the split's end are clamped and get factor 0, columns past ns are clamped
+// (their products land in entries that the slab sum never reads).
+constexpr int GL_KC = 8;                                  // rows per stage
+constexpr int GL_STRIP = GL_KC * TS * 16;                 // one strip: 16 KiB
+constexpr int GL_STAGE = 2 * GL_STRIP + 256;              // A strip, B strip, row factors
 
 __global__ void __launch_bounds__(256, 2)
 gram_kernel(const f64x2* __restrict__ R, const f64x2* __restrict__ rows, long long m, int ns,
             int ntiles, long long rows_per_split, double* __restrict__ slabs) {
+  __shared__ __align__(16) unsigned char smem[2 * GL_STAGE];
   int tile, split;
   block_work(blockIdx.x, ntiles, &tile, &split);
   int ti, tj;
   tile_of(tile, &ti, &tj);
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  int wr = wave >> 1, wc = wave & 1;
-  long long k_begin = (long long)split * rows_per_split;
-  long long k_end = k_begin + rows_per_split;
-  if (k_end > m) k_end = m;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wr = wave >> 1, wc = wave & 1;
+  const int lr = lane & 15, g = lane >> 4;
+  const long long k_begin = (long long)split * rows_per_split;
+  const long long k_end = min(k_begin + rows_per_split, m);
 
   f64x4 acc[4][4];
 #pragma unroll
@@ -216,14 +177,94 @@ gram_kernel(const f64x2* __restrict__ R, const f64x2* __restrict__ rows, long lo
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  int colA = ti * TS + wr * 64 + (lane & 15);
-  int colB = tj * TS + wc * 64 + (lane & 15);
   if (k_begin < k_end) {
-    bool edge = (ti + 1) * TS > ns;  // ti >= tj, so only the row-tile can overhang
-    if (edge)
-      gram_rows_loop<true>(R, rows, k_begin, k_end, ns, colA, colB, lane, acc);
-    else
-      gram_rows_loop<false>(R, rows, k_begin, k_end, ns, colA, colB, lane, acc);
+    const int nchunk = (int)((k_end - k_begin + GL_KC - 1) / GL_KC);
+    // LDS-DMA (hand-written: see gram_uniform_kernel): a strip is 16 pieces of 1 KiB = (row r,
+    // 64-column half h); wave w issues pieces w, w + 4, ... of the 32: the first four belong to the
+    // A strip, the last four to the B strip.  The per-lane byte offset of a piece (without the
+    // row, which is added as a uniform) fits 32 bits for one chunk.
+    unsigned off[8];
+    int prow[8];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      const int q = (wave + 4 * i) & 15;             // piece inside its strip
+      const int col0 = (i < 4 ? ti : tj) * TS + (q & 1) * 64 + lane;
+      prow[i] = q >> 1;
+      off[i] = (unsigned)min(col0, ns - 1) * 16u;
+    }
+    const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+        (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+    auto issue = [&](int ch, int buf, int i0, int i1) {
+      const long long r0 = k_begin + (long long)ch * GL_KC;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        if (i >= i0 && i < i1) {
+          const long long row = min(r0 + prow[i], k_end - 1);
+          const char* src = reinterpret_cast<const char*>(R + (size_t)row * ns);   // uniform
+          const unsigned dst = lds_base + (unsigned)(buf * GL_STAGE + (i < 4 ? 0 : GL_STRIP)) +
+                               (unsigned)(((wave + 4 * i) & 15) * 1024);
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                       :: "s"(dst), "v"(off[i]), "s"(src) : "memory");
+        }
+      }
+      if (rows && wave == 0 && i1 == 8) {            // the chunk's 8 row factors: 8 lanes
+        const long long row = min(r0 + (lane & 7), k_end - 1);
+        const unsigned woff = (unsigned)((row - r0) * 16);
+        const char* src = reinterpret_cast<const char*>(rows + r0);
+        const unsigned dst = lds_base + (unsigned)(buf * GL_STAGE + 2 * GL_STRIP);
+        if (lane < 8)
+          asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                       :: "s"(dst), "v"(woff), "s"(src) : "memory");
+      }
+    };
+    issue(0, 0, 0, 8);
+
+    const unsigned char* rdA = smem + (wr * 64 + lr) * 16 + g * (TS * 16);
+    const unsigned char* rdB = smem + GL_STRIP + (wc * 64 + lr) * 16 + g * (TS * 16);
+    for (int ch = 0; ch < nchunk; ++ch) {
+      const int buf = ch & 1;
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk ch have landed
+      __syncthreads();                                   // ... everyone's; the other stage is free
+      const bool more = ch + 1 < nchunk;
+      const unsigned char* sa = rdA + buf * GL_STAGE;
+      const unsigned char* sb = rdB + buf * GL_STAGE;
+      const long long r0 = k_begin + (long long)ch * GL_KC;
+      f64x2 a[2][4], b[2][4];
+      double w[2];
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          a[h][mi] = *reinterpret_cast<const f64x2*>(sa + h * 4 * (TS * 16) + mi * 256);
+          b[h][mi] = *reinterpret_cast<const f64x2*>(sb + h * 4 * (TS * 16) + mi * 256);
+        }
+        double wv = 1.0;
+        if (rows) {
+          f64x2 c = *reinterpret_cast<const f64x2*>(smem + buf * GL_STAGE + 2 * GL_STRIP +
+                                                    (h * 4 + g) * 16);
+          wv = c.x * c.x + c.y * c.y;
+        }
+        w[h] = (r0 + h * 4 + g < k_end) ? wv : 0.0;
+      }
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int h = 0; h < 2; ++h) {
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const double ax = a[h][mi].x * w[h];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(ax, b[h][ni].x, acc[mi][ni]);
+          if (more && h == 0) issue(ch + 1, buf ^ 1, mi, mi + 1);
+        }
+#pragma unroll
+        for (int mi = 0; mi < 4; ++mi) {
+          const double ay = a[h][mi].y * w[h];
+#pragma unroll
+          for (int ni = 0; ni < 4; ++ni) acc[mi][ni] = mfma(ay, b[h][ni].y, acc[mi][ni]);
+          if (more && h == 0) issue(ch + 1, buf ^ 1, 4 + mi, 5 + mi);
+        }
+      }
+    }
   }
   store_tile(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, wr, wc, lane);
 }
