@@ -307,6 +307,125 @@ apply_V_mfma_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                   : f64x2{p1[p][g], p2[p][g]};
 }
 
+// ---- the same product for 65 .. 144 antennas -----------------------------------------------------
+// The upper-triangular 16 x 16 blocks of C no longer fit one wave's registers (36 blocks x 3
+// products at 127 antennas), so a WORKGROUP of 8 waves owns an (f,t) (or one source range of it) and
+// splits the blocks, row-major, in runs of MAXB; the voltages of 32 sources x all antennas are
+// staged in LDS (two buffers, LDS-DMA written by hand as in gram_uniform_kernel so that the
+// compiler's waits stay counted), and every wave reads the A (row block) and B (column block)
+// operand of each of its blocks from there: element (antenna a, source s) sits at slot
+// s ^ (a & 15) of its row (the per-lane DMA source address does the swizzle), which spreads the 16
+// lanes of a read over all banks.  Three real products per complex one, as above.  Runs shorter
+// than MAXB are padded with block (0,0), whose second result is dropped.  Two 32-source tiles of
+// up to 144 antennas fit the 160 KiB of LDS; larger arrays keep the pair loop.
+constexpr int AVB_SRC = 32;
+constexpr int AVB_THREADS = 512;
+
+template <int MAXB>
+__global__ void __launch_bounds__(AVB_THREADS)
+apply_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int nr,
+                   const double* __restrict__ x, int nsplit, int tiles_per_split,
+                   f64x2* __restrict__ Cmat) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nap = 16 * nr, rows = nap;
+  const int tile_bytes = rows * AVB_SRC * 16 + AVB_SRC * 16;    // voltages, then x (padded to 16 B)
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int ft = blockIdx.x / nsplit, sp = blockIdx.x % nsplit;
+  const int ntile = (ns + AVB_SRC - 1) / AVB_SRC;
+  const int t0 = sp * tiles_per_split, t1 = min(t0 + tiles_per_split, ntile);
+
+  // this wave's blocks: entries q0 .. q0 + MAXB - 1 of the row-major list of upper blocks
+  const int nblk = nr * (nr + 1) / 2;
+  int brow[MAXB], bcol[MAXB];
+  {
+    int q0 = wave * MAXB, rb = 0, base = 0;
+    while (rb < nr && base + (nr - rb) <= q0) { base += nr - rb; ++rb; }
+    int cb = rb + (q0 - base);
+#pragma unroll
+    for (int q = 0; q < MAXB; ++q) {
+      const bool ok = q0 + q < nblk;
+      brow[q] = ok ? rb : -1;              // padding: multiplies block (0,0) again, never stored
+      bcol[q] = ok ? cb : 0;
+      if (++cb >= nr) { ++rb; cb = rb; }
+    }
+  }
+
+  // staging: a piece = 2 antenna rows x 32 sources = 1 KiB; wave w issues pieces w, w + 8, ...;
+  // rows beyond Nant repeat row Nant-1 (never gathered), sources beyond Ns repeat source Ns-1
+  // (their x is 0).  x: one 256-byte piece by wave 0.
+  const f64x2* vft = V + (size_t)ft * nant * ns;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+  const int npiece = nap / 2;
+  auto stage = [&](int t, int buf) {
+    const int s0 = t * AVB_SRC;
+    for (int q = wave; q < npiece; q += 8) {
+      const int a = min(2 * q + (lane >> 5), nant - 1);
+      const int sl = (lane & 31) ^ ((2 * q + (lane >> 5)) & 15);
+      const unsigned off = (unsigned)min(s0 + sl, ns - 1) * 16u;
+      const char* src = reinterpret_cast<const char*>(vft);
+      const unsigned long long rowoff = (unsigned long long)a * ns * 16ull + off;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * tile_bytes + q * 1024));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                   :: "s"(dst), "v"(src + rowoff) : "memory");
+    }
+    if (wave == 0 && x) {                 // 32 doubles of x as 64 dwords, one per lane
+      const long long dw = min((long long)s0 * 2 + lane, 2LL * ns - 1);
+      const char* src = reinterpret_cast<const char*>(x) + dw * 4;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(
+          lds_base + (unsigned)(buf * tile_bytes + rows * AVB_SRC * 16));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                   :: "s"(dst), "v"(src) : "memory");
+    }
+  };
+
+  f64x4 p1[MAXB], p2[MAXB], p3[MAXB];
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    p1[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    p2[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    p3[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  if (t0 < t1) stage(t0, 0);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // tile t has landed; the other buffer is free
+    if (t + 1 < t1) stage(t + 1, buf ^ 1);
+    const unsigned char* tb = smem + buf * tile_bytes;
+    const double* xs = reinterpret_cast<const double*>(tb + rows * AVB_SRC * 16);
+    const int s0 = t * AVB_SRC;
+#pragma unroll 2
+    for (int k = 0; k < AVB_SRC / 4; ++k) {
+      const int sl = 4 * k + g;                                 // source within the tile
+      double xv = x ? xs[sl] : 1.0;
+      if (s0 + sl >= ns) xv = 0.0;
+#pragma unroll
+      for (int q = 0; q < MAXB; ++q) {
+        const int ra = max(brow[q], 0) * 16 + lr, rc = bcol[q] * 16 + lr;
+        const f64x2 av = *reinterpret_cast<const f64x2*>(tb + (ra * AVB_SRC + (sl ^ lr)) * 16);
+        const f64x2 bv = *reinterpret_cast<const f64x2*>(tb + (rc * AVB_SRC + (sl ^ lr)) * 16);
+        const double ax = av.x * xv, ay = av.y * xv;
+        p1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bv.x, p1[q], 0, 0, 0);
+        p2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bv.y, p2[q], 0, 0, 0);
+        p3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax - ay, bv.x + bv.y, p3[q], 0, 0, 0);
+      }
+    }
+  }
+  f64x2* cm = Cmat + ((size_t)sp * nft + ft) * nap * nap;
+#pragma unroll
+  for (int q = 0; q < MAXB; ++q) {
+    if (brow[q] >= 0) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        cm[(size_t)(brow[q] * 16 + g + 4 * e) * nap + bcol[q] * 16 + lr] =
+            f64x2{p1[q][e] + p2[q][e], p3[q][e] - p1[q][e] + p2[q][e]};
+    }
+  }
+}
+
 // out[b,ft] = rowmul[b,ft] * sum_split C[split][ft][i_b][j_b]; entries below the block diagonal
 // are the conjugates of the stored upper blocks
 __global__ void __launch_bounds__(256)
@@ -916,8 +1035,23 @@ static void apply_V_mfma_plan(int nft, int ns, int* nsplit, int* k_per_split) {
   *k_per_split = ((nk + want - 1) / want + 3) / 4 * 4;   // k-steps per wave, whole groups of 4
 }
 
+// source tiles per workgroup of apply_V_big_kernel: whole (f,t) unless there are few of them
+static void apply_V_big_plan(int nft, int ns, int* nsplit, int* tiles_per_split) {
+  const int ntile = (ns + AVB_SRC - 1) / AVB_SRC;
+  int want = 1;
+  while (want < 64 && (long long)nft * want < 1024 && ntile / (2 * want) >= 8) want *= 2;
+  *tiles_per_split = (ntile + want - 1) / want;
+  *nsplit = (ntile + *tiles_per_split - 1) / *tiles_per_split;
+}
+
 size_t hydra_apply_V_workspace_bytes(int nf, int nt, int nant, int ns) {
-  if (nf <= 0 || nt <= 0 || nant <= 0 || ns <= 0 || nant > 64) return 0;
+  if (nf <= 0 || nt <= 0 || nant <= 0 || ns <= 0 || nant > 144) return 0;
+  if (nant > 64) {
+    int nsplit, tps;
+    apply_V_big_plan(nf * nt, ns, &nsplit, &tps);
+    size_t na = (size_t)(nant + 15) / 16 * 16;
+    return (size_t)nsplit * nf * nt * na * na * 16;
+  }
   int nsplit, kps;
   apply_V_mfma_plan(nf * nt, ns, &nsplit, &kps);
   size_t na = (size_t)(nant + 15) / 16 * 16;
@@ -937,8 +1071,40 @@ int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32
     return fail(HYDRA_ERR_WORKSPACE, "hydra_apply_V: workspace too small (%zu < %zu bytes)",
                 workspace_bytes, need);
   int nft = nf * nt, nsplit, kps;
-  apply_V_mfma_plan(nft, ns, &nsplit, &kps);
   int nr = (nant + 15) / 16;
+  if (nant > 64) {
+    int tps;
+    apply_V_big_plan(nft, ns, &nsplit, &tps);
+    HYDRA_CHECK_ARG((long long)nft * nsplit <= 2147483647LL, "hydra_apply_V: too many (f,t)");
+    const int nblk = nr * (nr + 1) / 2, maxb = (nblk + 7) / 8;
+    const size_t lds = 2 * ((size_t)(16 * nr) * AVB_SRC * 16 + AVB_SRC * 16);
+    hipStream_t st = as_stream(stream);
+    const f64x2* Vp = reinterpret_cast<const f64x2*>(V);
+    f64x2* cm = static_cast<f64x2*>(workspace);
+    unsigned grid = (unsigned)(nft * nsplit);
+#define HYDRA_AVB_LAUNCH(MB)                                                                       \
+  do {                                                                                             \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&apply_V_big_kernel<MB>), lds)) return rc; \
+    apply_V_big_kernel<MB><<<grid, AVB_THREADS, lds, st>>>(Vp, nft, nant, ns, nr, x, nsplit, tps, cm); \
+  } while (0)
+    switch (maxb) {
+      case 2: HYDRA_AVB_LAUNCH(2); break;
+      case 3: HYDRA_AVB_LAUNCH(3); break;
+      case 4: HYDRA_AVB_LAUNCH(4); break;
+      case 5: HYDRA_AVB_LAUNCH(5); break;
+      case 6: HYDRA_AVB_LAUNCH(6); break;
+      default: HYDRA_AVB_LAUNCH(7); break;
+    }
+#undef HYDRA_AVB_LAUNCH
+    HYDRA_CHECK_LAUNCH("hydra_apply_V(antenna space)");
+    size_t n = (size_t)nbl * nft;
+    apply_V_gather_kernel<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
+        cm, nft, nr * 16, nsplit, bl_i, bl_j, nbl, reinterpret_cast<const f64x2*>(rowmul),
+        reinterpret_cast<f64x2*>(out));
+    HYDRA_CHECK_LAUNCH("hydra_apply_V(gather)");
+    return HYDRA_OK;
+  }
+  apply_V_mfma_plan(nft, ns, &nsplit, &kps);
   long long nwaves = (long long)nft * nsplit;
   unsigned grid = (unsigned)((nwaves + 3) / 4);
   hipStream_t st = as_stream(stream);

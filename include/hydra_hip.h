@@ -257,8 +257,11 @@ int hydra_adjoint_R(const double* R, long long m, int ns, const double* z, const
  *   out[b,f,t] = gg[b,f,t] * sum_s conj(V[f,t,i_b,s]) V[f,t,j_b,s] x[s]     (x NULL = ones)
  *   out[s]     = scale[s] * sum_{b,f,t} Re( conj(conj(V_i) V_j) z[b,f,t] ) + add[s]
  * For Nant <= 64 both run in antenna space on the matrix cores (C = conj(V) diag(x) V^T and
- * W = Zc V per (f,t)); hydra_apply_V then needs hydra_apply_V_workspace_bytes() of workspace
- * (with workspace == NULL, or Nant > 64, it loops over the baselines instead).              */
+ * W = Zc V per (f,t)); hydra_apply_V does so up to 144 antennas (from 65 on a workgroup shares
+ * the blocks of C and stages the voltages through LDS) and then needs
+ * hydra_apply_V_workspace_bytes() of workspace (with workspace == NULL, or more antennas, it
+ * loops over the baselines instead).  The adjoint for 65 .. 160 antennas:
+ * hydra_adjoint_V_antspace below.                                                           */
 size_t hydra_apply_V_workspace_bytes(int nf, int nt, int nant, int ns);
 int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32_t* bl_i,
                   const int32_t* bl_j, int nbl, const double* x, const double* rowmul,

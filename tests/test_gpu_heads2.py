@@ -595,6 +595,31 @@ def test_antenna_space_adjoint_for_more_than_64_antennas(hex_spec, ns, nf, nt):
     got2 = fac2.adjoint(z2d).cpu().numpy()
     assert relerr(got2, want2) < 1e-12
 
+    # R x in antenna space (apply_V_big_kernel from 65 antennas on) against the pair loop and the
+    # oracle's R @ x; x = None (ones), a row factor, and the list with autos / missing pairs
+    from hydra_amd import _dev
+    x = rng.randn(ns)
+    xd = torch.as_tensor(x, device=fac.V.device)
+    rm = torch.as_tensor(rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt), device=fac.V.device)
+
+    def both(f, xx, rowmul=None):
+        res = []
+        for enable in (0, 1):
+            prev = _dev._lib.query("hydra_debug_adjoint_mfma", enable)
+            try:
+                res.append(f.apply(xx, rowmul=rowmul).cpu().numpy())
+            finally:
+                _dev._lib.query("hydra_debug_adjoint_mfma", prev)
+        return res
+    pair, ant = both(fac, xd)
+    assert relerr(ant, pair) < 1e-12
+    assert operr(ant, (R @ x).reshape(nbl, nf, nt)) < OP_TOL
+    pair, ant = both(fac, None, rowmul=rm)
+    assert relerr(ant, pair) < 1e-12
+    assert operr(ant, rm.cpu().numpy() * R.sum(axis=1).reshape(nbl, nf, nt)) < OP_TOL
+    pair, ant = both(fac2, xd)
+    assert relerr(ant, pair) < 1e-12
+
 
 @pytest.mark.parametrize("nant,nft", [(380, 21), (430, 10), (9, 3)])
 def test_streamed_gain_pairs_layouts(hy, nant, nft):
