@@ -971,11 +971,13 @@ def main():
                     help="skip the extra launches of the general Gram kernel after the timed region")
     ap.add_argument("--shard", default=None, choices=["freq", "baseline"],
                     help="how the visibility rows are split over GPUs (default: freq; c5s: baseline)")
-    ap.add_argument("--solver", default=None, choices=["dense", "cg", "cg-rows"],
+    ap.add_argument("--solver", default=None, choices=["dense", "cg", "cg-rows", "dense-rows"],
                     help="dense = blocked Cholesky (the reference's default for this head, "
                          "example.py:944); cg = linear_solver.cg on the root; cg-rows = the operator "
                          "stays sharded by rows over the GPUs and every rank runs the CG with a "
-                         "row-block product + all-gather per iteration (config 5 on > 1 GPU)")
+                         "row-block product + all-gather per iteration; dense-rows = the same "
+                         "layout factored in place by the row-sharded Cholesky "
+                         "(linear_solver.solve_dense_rows; config 5 on > 1 GPU)")
     args = ap.parse_args()
 
     import torch
@@ -1005,12 +1007,14 @@ def main():
     shard = args.shard or ("baseline" if args.config == "c5s" else "freq")
     if args.solver is None:
         # one GPU factors the operator (config 5: 80 GB, 5.7 s); with more GPUs config 5 keeps the
-        # summed Gram sharded by rows and every rank runs the CG on its rows
-        args.solver = "cg-rows" if (args.config == "c5" and world > 1) else "dense"
+        # summed Gram sharded by rows and the ranks factor it together
+        args.solver = "dense-rows" if (args.config == "c5" and world > 1) else "dense"
     if args.config == "c5":
         args.no_cpu = True     # the CPU path cannot form or solve a 100 000^2 system in minutes
     if args.solver == "cg-rows" and world == 1:
         args.solver = "cg"
+    if args.solver == "dense-rows" and world == 1:
+        args.solver = "dense"
     inp = synth_inputs(hex_spec, ns, nf, nt, outriggers=19 if big else 0)
     ant_pos, antpairs_all = inp["ant_pos"], inp["antpairs"]
     nant = len(ant_pos)
@@ -1072,6 +1076,17 @@ def main():
             x, iters = hy.linear_solver.cg(None, b, maxiters=1000, abs_tol=args.cg_tol,
                                            linear_op=op, return_iters=True)
             return op, b, x, iters
+        if args.solver == "dense-rows":
+            A, b = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
+                                                inv_noise, gains, prior, omega_n=om_n, omega_a=om_a,
+                                                shard_rows=True)
+            ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
+            keep = A.clone() if ns <= 20000 else None
+            ev[0].record()
+            x = hy.linear_solver.solve_dense_rows(comm, A, b, overwrite_a=True)
+            ev[1].record()
+            solve_events.append(ev)
+            return keep, b, x, 0
         A, b = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
                                             inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
         if rank == 0 and args.solver == "cg":
@@ -1125,10 +1140,16 @@ def main():
     # sanity of the last sample (outside the timed region; the row-sharded product is collective).
     # The in-place factorisation of the 80 GB operator consumed it: rebuild it from the same
     # inputs (same Gram; b and x belong to the last sample's fluctuation draws, which only enter b)
-    if A is None and rank == 0:
+    if args.solver == "dense-rows":
+        if A is None:
+            A, _ = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
+                                                inv_noise, gains, prior, realisation=False,
+                                                shard_rows=True)
+        A = hy.linear_solver.RowShardedOperator(comm, A, ns)
+    elif A is None and rank == 0:
         A, _ = ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs_loc, times, fac, data,
                                             inv_noise, gains, prior, realisation=False)
-    Ax = A(x) if args.solver == "cg-rows" else (A @ x if rank == 0 else None)
+    Ax = A(x) if args.solver in ("cg-rows", "dense-rows") else (A @ x if rank == 0 else None)
     if rank != 0:
         return
     resid = float((torch.linalg.norm(Ax - b) / torch.linalg.norm(b)).item())
@@ -1219,12 +1240,17 @@ def main():
     if solve_events:
         fl = ns ** 3 / 3.0
         s_ach = fl / (solve_ms * 1e-3) / 1e12
+        solve_gpus = world if args.solver == "dense-rows" else 1
         out["dense_solve"] = {
-            "kernel": ("chol_syrk_mfma_kernel (256-wide-panel Cholesky, trailing update on the FP64 "
+            "kernel": ("row-sharded 256-wide-panel Cholesky over the ranks (solve_dense_rows: panel "
+                       "all-gather + chol_syrk_mfma_kernel on each rank's rows)"
+                       if args.solver == "dense-rows" else
+                       "chol_syrk_mfma_kernel (256-wide-panel Cholesky, trailing update on the FP64 "
                        "matrix cores) + panel steps + triangular solves" if ns >= 6144 else
                        "32-wide blocked Cholesky (launch-chain bound at this size)"),
             "n": ns, "ms": solve_ms, "flops": fl, "bound": "mfma", "achieved": s_ach,
-            "peak": FP64_MATRIX_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": s_ach / FP64_MATRIX_PEAK_TFLOPS,
+            "peak": FP64_MATRIX_PEAK_TFLOPS * solve_gpus, "unit": "TFLOP/s",
+            "frac": s_ach / (FP64_MATRIX_PEAK_TFLOPS * solve_gpus), "gpus": solve_gpus,
         }
     if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         nf_s, nt_s = (2, 10) if args.config == "c2" else (min(nf, 2), min(nt, 10))

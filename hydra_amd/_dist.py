@@ -185,6 +185,20 @@ class Comm:
         self.allreduce_(packed)
         return self._sym_unpack(packed, A)
 
+    def allgather_into_(self, out, part):
+        """``out`` (size * m, ...) <- the ranks' equally shaped ``part`` (m, ...) in rank order:
+        one ``all_gather_into_tensor`` on RCCL, no concatenation copy."""
+        if self.backend == "nccl" and out.is_cuda and out.is_contiguous() and part.is_contiguous():
+            dist.all_gather_into_tensor(out, part, group=self.group)
+            return out
+        s, _ = self._stage(part)
+        parts = [torch.empty_like(s) for _ in range(self.Get_size())]
+        dist.all_gather(parts, s, group=self.group)
+        m = part.shape[0]
+        for k, p in enumerate(parts):
+            out[k * m:(k + 1) * m].copy_(p)
+        return out
+
     def allgather_rows(self, part, n):
         """Concatenate the ranks' row-block vectors (lengths as in ``row_range``) into the full
         length-n vector on every rank."""

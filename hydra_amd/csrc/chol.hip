@@ -329,6 +329,7 @@ constexpr int KC = 16;            // k-values per LDS stage
 constexpr int NKC = PB / KC;
 constexpr int STG_BYTES = 2 * CT * KC * 8;   // one stage: A strip + B strip = 32 KiB
 constexpr int SUP = 8;            // tiles per edge of the patch one XCD works on at a time
+constexpr int PB_WIDTH_ABI = PB;  // hydra_chol_update_rect: K of the update
 
 __device__ __forceinline__ void tri_of(int p, int* i, int* j) {   // p = i (i+1)/2 + j, j <= i
   int a = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
@@ -342,31 +343,45 @@ __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
   return __builtin_amdgcn_mfma_f64_16x16x4f64(a, b, c, 0, 0, 0);
 }
 
+// General form: C[i][j] -= sum_k PA[i][k] PB[j][k] (k < 256) for i < mrows, j < ncols and
+// j <= i + diag.  The factorisation of one matrix calls it with C, PA, PB inside that matrix
+// (triangular tile order below); the row-sharded factorisation (hydra_chol_update_rect) with a
+// rank's own rows as C / PA and the gathered panel as PB (plain 2-D tile order, tiles entirely
+// above the diagonal leave at once).
 __global__ void __launch_bounds__(256, 2)
-chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
+chol_syrk_mfma_kernel(double* __restrict__ C, long long ldc, const double* __restrict__ PA,
+                      long long lda, const double* __restrict__ PB, long long ldb, int mrows,
+                      int ncols, int diag, int ntr, int nsup, int ntc) {
   __shared__ __align__(16) unsigned char smem[2 * STG_BYTES];
-  // block -> tile: blocks with equal id % 8 share an XCD (round-robin dispatch) and walk one
-  // 8 x 8 patch of tiles after another, so the ~64 tiles resident on an XCD share 16 row strips
-  const int id = blockIdx.x, slot = id >> 3;
-  const int sidx = (slot / (SUP * SUP)) * 8 + (id & 7);
-  if (sidx >= nsup) return;
-  int si, sj;
-  tri_of(sidx, &si, &sj);
-  const int within = slot % (SUP * SUP);
-  const int ti = si * SUP + within / SUP, tj = sj * SUP + within % SUP;
-  if (ti >= ntr || tj > ti) return;
+  int ti, tj;
+  if (nsup > 0) {
+    // block -> tile: blocks with equal id % 8 share an XCD (round-robin dispatch) and walk one
+    // 8 x 8 patch of tiles after another, so the ~64 tiles resident on an XCD share 16 row strips
+    const int id = blockIdx.x, slot = id >> 3;
+    const int sidx = (slot / (SUP * SUP)) * 8 + (id & 7);
+    if (sidx >= nsup) return;
+    int si, sj;
+    tri_of(sidx, &si, &sj);
+    const int within = slot % (SUP * SUP);
+    ti = si * SUP + within / SUP;
+    tj = sj * SUP + within % SUP;
+    if (ti >= ntr || tj > ti) return;
+  } else {
+    ti = blockIdx.x / ntc;
+    tj = blockIdx.x % ntc;
+    if (ti >= ntr || (long long)tj * CT > (long long)ti * CT + CT - 1 + diag) return;
+  }
 
-  const int t0 = k + PB;
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wr = wave >> 1, wc = wave & 1;
   const int lr = lane & 15, g = lane >> 4;
-  const int rowA0 = t0 + ti * CT, rowB0 = t0 + tj * CT;
+  const int rowA0 = ti * CT, rowB0 = tj * CT;
 
   // LDS-DMA: a stage is 32 pieces of 1 KiB (8 rows x 128 B); wave w issues pieces w, w+4, ...:
   // the first four belong to the A strip, the last four to the B strip.  Rows past the matrix
   // are clamped (their products land in rows / columns that are not stored).
-  const char* baseA = reinterpret_cast<const char*>(A + (size_t)rowA0 * n + k);
-  const char* baseB = reinterpret_cast<const char*>(A + (size_t)rowB0 * n + k);
+  const char* baseA = reinterpret_cast<const char*>(PA + (size_t)rowA0 * lda);
+  const char* baseB = reinterpret_cast<const char*>(PB + (size_t)rowB0 * ldb);
   unsigned off[8];
 #pragma unroll
   for (int i = 0; i < 8; ++i) {
@@ -374,8 +389,8 @@ chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
     const int pr = (q & 15) * 8 + (lane >> 3);
     const int c = (lane & 7) ^ ((pr >> 1) & 7);
     const int row0 = (i < 4) ? rowA0 : rowB0;
-    const int gr = min(row0 + pr, n - 1) - row0;
-    off[i] = (unsigned)gr * (unsigned)n * 8u + (unsigned)c * 16u;
+    const int gr = min(row0 + pr, ((i < 4) ? mrows : ncols) - 1) - row0;
+    off[i] = (unsigned)gr * (unsigned)((i < 4) ? lda : ldb) * 8u + (unsigned)c * 16u;
   }
   // (LDS-DMA by hand-written asm: through the compiler's builtin every later wait in the wave
   // becomes lgkmcnt(0) / vmcnt(0) while a DMA may be in flight -- see gram_uniform_kernel)
@@ -403,8 +418,8 @@ chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
     for (int ni = 0; ni < 4; ++ni)
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        int gi = min(ci + mi * 16 + 4 * e, n - 1), gj = min(cj + ni * 16, n - 1);
-        acc[mi][ni][e] = -A[(size_t)gi * n + gj];
+        int gi = min(ci + mi * 16 + 4 * e, mrows - 1), gj = min(cj + ni * 16, ncols - 1);
+        acc[mi][ni][e] = -C[(size_t)gi * ldc + gj];
       }
 
   const int swz = (lr >> 1) & 7;
@@ -465,7 +480,7 @@ chol_syrk_mfma_kernel(double* __restrict__ A, int n, int k, int ntr, int nsup) {
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
         int gi = ci + mi * 16 + 4 * e, gj = cj + ni * 16;
-        if (gi < n && gj <= gi) A[(size_t)gi * n + gj] = -acc[mi][ni][e];
+        if (gi < mrows && gj < ncols && gj <= gi + diag) C[(size_t)gi * ldc + gj] = -acc[mi][ni][e];
       }
 }
 
@@ -575,7 +590,9 @@ static int chol_factor_blocked(double* A, int n, int32_t* info_dev, hipStream_t 
       const long long nsup = (long long)nsr * (nsr + 1) / 2;
       const long long grid = (nsup + 7) / 8 * 8 * SUP * SUP;
       if (grid > 2147483647LL) return fail(HYDRA_ERR_ARG, "hydra_chol_solve: n=%d is too large", n);
-      chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, s>>>(A, n, k, ntr, (int)nsup);
+      const double* P = A + (size_t)col_end * n + k;            // the finished panel, in place
+      chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, s>>>(A + (size_t)col_end * n + col_end, n, P, n,
+                                                           P, n, rest, rest, 0, ntr, (int)nsup, ntr);
     }
   }
   HYDRA_CHECK_LAUNCH("hydra_chol_solve(blocked factor)");
@@ -627,6 +644,27 @@ int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, voi
   int rc = chol_factor_blocked(A, n, info_dev, s);
   if (rc || !b) return rc;
   return chol_solve_blocked(A, b, n, s);
+}
+
+int hydra_chol_update_rect(double* C, long long ldc, const double* PA, long long lda,
+                           const double* PB, long long ldb, int mrows, int ncols, int diag,
+                           void* stream) {
+  HYDRA_CHECK_ARG(C && PA && PB && mrows > 0 && ncols > 0 && ldc >= ncols && lda >= PB_WIDTH_ABI &&
+                      ldb >= PB_WIDTH_ABI,
+                  "hydra_chol_update_rect: bad arguments (mrows=%d ncols=%d)", mrows, ncols);
+  HYDRA_CHECK_ARG(reinterpret_cast<uintptr_t>(PA) % 16 == 0 && reinterpret_cast<uintptr_t>(PB) % 16 == 0 &&
+                      lda % 2 == 0 && ldb % 2 == 0,
+                  "hydra_chol_update_rect: operand rows must be 16-byte aligned");
+  HYDRA_CHECK_ARG((unsigned long long)lda * 8ull * (unsigned)CT < 4294967296ull &&
+                      (unsigned long long)ldb * 8ull * (unsigned)CT < 4294967296ull,
+                  "hydra_chol_update_rect: leading dimension too large");
+  const int ntr = (mrows + CT - 1) / CT, ntc = (ncols + CT - 1) / CT;
+  const long long grid = (long long)ntr * ntc;
+  HYDRA_CHECK_ARG(grid <= 2147483647LL, "hydra_chol_update_rect: too many tiles");
+  chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(C, ldc, PA, lda, PB, ldb, mrows,
+                                                                       ncols, diag, ntr, 0, ntc);
+  HYDRA_CHECK_LAUNCH("hydra_chol_update_rect");
+  return HYDRA_OK;
 }
 
 }  // extern "C"

@@ -230,6 +230,108 @@ class RowShardedOperator:
         return _dev.like(v, self.comm.allgather_rows(self.y[:nloc], self.n))
 
 
+def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
+    """The dense solve of the driver (``scipy.linalg.solve(A, b, assume_a='her')``,
+    example.py:940-947) for an operator sharded by rows over the ranks of ``comm`` -- the layout
+    ``precompute_mpi(..., shard_rows=True)`` leaves it in: rank k holds rows
+    ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n), ``bvec`` (n,) is the same on every rank.
+    Returns x (n,) on every rank.
+
+    Right-looking Cholesky with 256-wide panels, every rank working on its own rows: per panel the
+    256 x 256 diagonal block is summed to all ranks (each owns some of its rows) and factored by
+    everyone, every rank solves its rows of the panel against it, the panel is all-gathered
+    (n x 256 doubles), and every rank updates its rows of the trailing matrix on the FP64 matrix
+    cores (``hydra_chol_update_rect``, the kernel of the one-GPU factorisation).  The two
+    triangular solves then walk the row blocks in order, one broadcast per block.  Work per rank
+    is its rows' share of the triangle (the last block has 2 - 1/size times the mean).
+    n must be even.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
+    A = _dev.f64(A_rows)
+    if not (overwrite_a and A is A_rows):
+        A = A.clone()
+    b = _dev.f64(bvec)
+    n = b.numel()
+    size, rank = comm.Get_size(), comm.Get_rank()
+    r0, r1 = comm.row_range(n)
+    nloc = r1 - r0
+    assert tuple(A.shape) == (nloc, n) and A.is_contiguous(), (tuple(A.shape), (r0, r1, n))
+    assert n % 2 == 0, "solve_dense_rows: n must be even (rows are moved in 16-byte pieces)"
+    per = -(-n // size)
+    dev, st = A.device, _dev.stream_ptr()
+    PBW = 256
+    info = _dev.zeros((1,), torch.int32)
+    bad = _dev.zeros((1,), torch.int32)
+    dummy = torch.zeros(PBW, dtype=torch.float64, device=dev)
+    # (rows above the panel's end are never read from these two: no clearing per panel)
+    mine = torch.zeros((per, PBW), dtype=torch.float64, device=dev)
+    panel = torch.empty((size * per, PBW), dtype=torch.float64, device=dev)
+    for k in range(0, n, PBW):
+        pb = min(PBW, n - k)
+        kend = k + pb
+        # diagonal block: every rank contributes the rows it owns
+        D = torch.zeros((pb, pb), dtype=torch.float64, device=dev)
+        d0, d1 = max(r0, k), min(r1, kend)
+        if d1 > d0:
+            D[d0 - k:d1 - k] = A[d0 - r0:d1 - r0, k:kend]
+        comm.allreduce_(D)
+        D = torch.tril(D)
+        D = D + torch.tril(D, -1).T
+        dummy.zero_()
+        _dev.call("hydra_chol_solve", _dev.ptr(D), _dev.ptr(dummy), pb, _dev.ptr(info), st)
+        bad |= info
+        L = torch.tril(D)
+        if d1 > d0:
+            A[d0 - r0:d1 - r0, k:kend] = L[d0 - k:d1 - k]
+        # this rank's rows of the panel below the block: X L^T = P
+        i0 = max(r0, kend)
+        rest = n - kend
+        if r1 > i0:
+            X = mine[i0 - r0:nloc] if rest > 0 else torch.empty((r1 - i0, pb), dtype=torch.float64,
+                                                                device=dev)
+            torch.linalg.solve_triangular(L.T, A[i0 - r0:, k:kend].contiguous(), upper=True,
+                                          left=False, out=X)
+            A[i0 - r0:, k:kend] = X
+        if rest <= 0:
+            break
+        # the whole panel, in global row order, on every rank
+        comm.allgather_into_(panel, mine)
+        if r1 > i0:
+            mrows, ncols = r1 - i0, r1 - kend
+            c_off = ((i0 - r0) * n + kend) * 8
+            a_off = ((i0 - r0) * n + k) * 8
+            _dev.call("hydra_chol_update_rect", A.data_ptr() + c_off, n, A.data_ptr() + a_off, n,
+                      panel.data_ptr() + kend * PBW * 8, PBW, mrows, ncols, i0 - kend, st)
+    comm.allreduce_(bad, op="max")
+    if int(bad.item()) != 0:
+        raise np.linalg.LinAlgError("matrix is not positive definite")
+    # L y = b, block row by block row
+    y = b.clone()
+    for s in range(size):
+        s0, s1 = comm.row_range(n, s)
+        if s1 <= s0:
+            continue
+        if rank == s:
+            rhs = y[s0:s1] - (A[:, :s0] @ y[:s0] if s0 > 0 else 0.0)
+            y[s0:s1] = torch.linalg.solve_triangular(A[:, s0:s1], rhs[:, None], upper=False)[:, 0]
+        comm.bcast_(y[s0:s1], root=s)
+    # L^T x = y, from the last block up
+    x = y
+    for s in range(size - 1, -1, -1):
+        s0, s1 = comm.row_range(n, s)
+        if s1 <= s0:
+            continue
+        c = torch.zeros(max(s0, 1), dtype=torch.float64, device=dev)
+        if rank == s:
+            xs = torch.linalg.solve_triangular(A[:, s0:s1].T, x[s0:s1][:, None], upper=True)[:, 0]
+            x[s0:s1] = xs
+            if s0 > 0:
+                c[:s0] = A[:, :s0].T @ xs
+        comm.bcast_(x[s0:s1], root=s)
+        if s0 > 0:
+            comm.bcast_(c, root=s)
+            x[:s0] -= c[:s0]
+    return _dev.like(bvec, x)
+
+
 # ------------------------------------------------------------------ 2-D block CG over ranks
 
 def matvec_mpi(comm_row, mat_block, vec_block):

@@ -475,6 +475,37 @@ def case_symreduce(comm):
     comm.barrier()
 
 
+def case_cholrows(comm):
+    """linear_solver.solve_dense_rows: Cholesky of a matrix sharded by rows over the ranks
+    (example.py:940-947 for an operator that stays sharded) against numpy's solve; sizes around
+    the 256-wide panels and with row blocks that cut through panels."""
+    from hydra_amd import linear_solver
+    rank, size = comm.Get_rank(), comm.Get_size()
+    dev = torch.device("cuda")
+    for n in (2, 254, 256, 258, 700, 1026):
+        rng = np.random.RandomState(n)
+        B = rng.randn(n, n + 5)
+        A = B @ B.T / n + np.eye(n)
+        b = rng.randn(n)
+        want = np.linalg.solve(A, b)
+        r0, r1 = comm.row_range(n)
+        rows = torch.as_tensor(A[r0:r1], device=dev).contiguous()
+        x = linear_solver.solve_dense_rows(comm, rows, torch.as_tensor(b, device=dev))
+        got = x.cpu().numpy()
+        assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want)), (n, np.max(np.abs(got - want)))
+        assert torch.equal(rows, torch.as_tensor(A[r0:r1], device=dev))      # input untouched
+    # not positive definite: every rank raises
+    A = -np.eye(300)
+    r0, r1 = comm.row_range(300)
+    try:
+        linear_solver.solve_dense_rows(comm, torch.as_tensor(A[r0:r1], device=dev).contiguous(),
+                                       torch.ones(300, dtype=torch.float64, device=dev))
+        raise AssertionError("no error for an indefinite matrix")
+    except np.linalg.LinAlgError:
+        pass
+    comm.barrier()
+
+
 def case_nccl1(comm):
     """Every collective of _dist.Comm on RCCL itself, with the one rank a 1-GPU box can hold:
     the nccl-only branches (GPU-resident numpy staging, reduce_scatter_tensor,
@@ -516,6 +547,7 @@ def case_nccl1(comm):
     b = torch.as_tensor(rng.randn(12), device=dev)
     xs = linear_solver.cg(None, b, linear_op=lambda p: Ad @ p, comm=comm, abs_tol=1e-12)
     assert float(torch.linalg.norm(Ad @ xs - b)) < 1e-9
+    case_cholrows(comm)
     comm.barrier()
 
 
@@ -535,7 +567,8 @@ if __name__ == "__main__":
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
          "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
          "rowshard": case_rowshard, "shmpi": case_shmpi, "gainmpi": case_gainmpi,
-         "symreduce": case_symreduce, "driver": case_driver, "nccl1": case_nccl1}[case](comm)
+         "symreduce": case_symreduce, "driver": case_driver, "nccl1": case_nccl1,
+         "cholrows": case_cholrows}[case](comm)
     except BaseException:
         import traceback
         if logdir:

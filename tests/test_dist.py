@@ -108,3 +108,13 @@ def test_driver_with_frequency_chunks_world2():
 def test_rccl_collectives_world1():
     """The nccl branches of _dist.Comm on a real RCCL communicator (one rank: a 1-GPU box)."""
     _run("nccl1", 1)
+
+
+@pytest.mark.gpu
+def test_row_sharded_cholesky_world2():
+    _run("cholrows", 2)
+
+
+@pytest.mark.gpu
+def test_row_sharded_cholesky_world3():
+    _run("cholrows", 3)

@@ -24,6 +24,7 @@ gains = torch.as_tensor(inp["g0"], device=dev)[:, None, None].expand(nant, nf, n
 w = torch.full((nbl, nf, nt), 400.0, dtype=torch.float64, device=dev)
 lib = _lib.load()
 buf = (ctypes.c_ulonglong * 8)()
+fac.allow_uniform = False
 fac.gram(gains, w); torch.cuda.synchronize()
 lib.hydra_debug_stamps(buf, 1)
 fac.gram(gains, w); torch.cuda.synchronize()
