@@ -11,8 +11,8 @@ Spherical-harmonic diffuse head on MI355X -- drop-in for the GCR functions of
 = Re(R^H y).  The reference evaluates the left-hand side left-to-right, i.e. it builds the
 (Nm, Nm) Gram on every CG iteration; here the same operator is applied as R^H (N^-1 (R a))
 (two passes over R, HBM bound), and ``lhs_matrix`` builds the Gram once on the FP64 matrix
-cores for callers that iterate many times.  GSM helpers / radiometer_eq / sample_cl of the
-reference module are outside the hot path (they need pygdsm data files) and are not provided.
+cores for callers that iterate many times.  The GSM helpers of the reference module need pygdsm
+data files and are not provided; ``sample_cl`` is a stub there.
 """
 import numpy as np
 import torch
@@ -84,6 +84,25 @@ def vis_proj_operator_no_rot(freqs, lsts, beams, ant_pos, lmax, nside,
         au = project(autos, None)          # the reference applies no spectral factor to autos
         return conv(resp), conv(au), ell, m
     return conv(resp), ell, m
+
+
+def radiometer_eq(auto_visibilities, ants, delta_time, delta_freq, Nnights=1, include_autos=False):
+    """Noise variance of every baseline from the auto-correlations (sh_sampler.py:497-522):
+    ``V_ii V_jj / (Nnights * delta_time * delta_freq)`` for the pairs i < j (i <= j with
+    ``include_autos``) in antenna order, each a block of ``len(auto_visibilities) // len(ants)``
+    samples; the blocks are concatenated.  ``ants`` are the block indices 0 .. Nants-1."""
+    autos = np.asarray(auto_visibilities.cpu() if _dev.is_torch(auto_visibilities)
+                       else auto_visibilities)
+    ants = [int(a) for a in ants]
+    indx = autos.shape[0] // len(ants)
+    blocks = autos[:indx * (max(ants) + 1)].reshape(max(ants) + 1, indx) if ants else autos[:0]
+    first = np.array([i for i in ants for j in ants if (j >= i if include_autos else j > i)],
+                     dtype=np.int64)
+    second = np.array([j for i in ants for j in ants if (j >= i if include_autos else j > i)],
+                      dtype=np.int64)
+    if first.size == 0:
+        return np.empty((0,))
+    return ((blocks[first] * blocks[second]) / (Nnights * delta_time * delta_freq)).reshape(-1)
 
 
 def alms2healpy(alms, lmax):

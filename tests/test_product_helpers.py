@@ -190,3 +190,17 @@ def test_config_flags_match_the_reference_parser():
     assert a.sample_ptsrc and a.sample_gains and not a.sample_sh
     assert a.hex_array == [4, 7] and a.Nptsrc == 50 and a.solver_name == "mpicg"
     assert a.ra_bounds == [0.1, 0.9] and a.gain_prior_zero_mode_std == 0.01
+
+
+def test_radiometer_eq_matches_the_reference():
+    """sh_sampler.radiometer_eq against the reference's outputs (tests/golden/radiometer.npz,
+    made by make_golden_radiometer.py from hydra/sh_sampler.py:497-522), bit for bit."""
+    from hydra_amd import sh_sampler
+    g = load_golden("radiometer.npz")
+    for tag in ("a", "b", "c"):
+        ants = np.arange(int(g[tag + "_nant"]))
+        got = sh_sampler.radiometer_eq(g[tag + "_autos"], ants, 10.7, 97.6e3)
+        assert got.shape == g[tag + "_cross"].shape and np.array_equal(got, g[tag + "_cross"])
+        got = sh_sampler.radiometer_eq(g[tag + "_autos"], ants, 10.7, 97.6e3, Nnights=3,
+                                       include_autos=True)
+        assert np.array_equal(got, g[tag + "_with_autos"])
