@@ -202,3 +202,45 @@ def status(myid, message, colour=None):
         print("%s%s %s%s" % (colours[colour], tag, message, "\033[0m"))
     else:
         print("%s %s" % (tag, message))
+
+
+def load_gain_model(gain_model_file, lst_pad=[0, 0], freq_pad=[0, 0], pad_value=1.0):
+    """Complex gain model (Nants, Nfreqs, Ntimes) from a ``.npy`` file, surrounded by
+    ``freq_pad`` / ``lst_pad`` = [before, after] samples of ``pad_value`` (utils.py:113-157)."""
+    model = np.load(gain_model_file)
+    nants, nf, nt = model.shape
+    out = np.full((nants, nf + freq_pad[0] + freq_pad[1], nt + lst_pad[0] + lst_pad[1]),
+                  pad_value, dtype=model.dtype)
+    out[:, freq_pad[0]:freq_pad[0] + nf, lst_pad[0]:lst_pad[0] + nt] = model
+    return out
+
+
+def extend_coords_with_padding(arr, pad=[0, 0]):
+    """An equally spaced coordinate array continued by ``pad`` = [before, after] extrapolated
+    samples (utils.py:261-288)."""
+    arr = np.asarray(arr)
+    step = arr[1] - arr[0]
+    head = arr[0] - step * (np.arange(pad[0]) + 1.0)[::-1]
+    tail = arr[-1] + step * (1.0 + np.arange(pad[1]))
+    return np.concatenate([head, arr, tail]).astype(arr.dtype)
+
+
+def gain_prior_pspec_sqrt(lsts, freqs, gain_prior_amp, gain_prior_sigma_frate=None,
+                          gain_prior_sigma_delay=None, gain_prior_zeropoint_std=None, frate0=0.0,
+                          delay0=0.0):
+    """Square root of the gain prior power spectrum on the (delay, fringe-rate) FFT grid,
+    (Nfreqs, Ntimes): flat at ``gain_prior_amp``, optionally Gaussian-tapered in fringe rate
+    (mHz, centre ``frate0``) and / or delay (ns, centre ``delay0``), the (0,0) mode optionally
+    pinned to ``gain_prior_zeropoint_std`` (utils.py:565-622).  ``lsts`` in radians, ``freqs`` in MHz."""
+    lsts, freqs = np.asarray(lsts), np.asarray(freqs)
+    secs = 24.0 * 60.0 * 60.0 * lsts / (2.0 * np.pi)
+    frate = 1e3 * np.fft.fftfreq(secs.size, d=secs[1] - secs[0])       # mHz
+    delay = 1e3 * np.fft.fftfreq(freqs.size, d=freqs[1] - freqs[0])    # ns
+    ps = gain_prior_amp * np.ones((freqs.size, secs.size))
+    if gain_prior_sigma_frate is not None:
+        ps *= np.exp(-0.5 * ((frate[np.newaxis, :] - frate0) / gain_prior_sigma_frate) ** 2.0)
+    if gain_prior_sigma_delay is not None:
+        ps *= np.exp(-0.5 * ((delay[:, np.newaxis] - delay0) / gain_prior_sigma_delay) ** 2.0)
+    if gain_prior_zeropoint_std is not None:
+        ps[delay == 0.0, frate == 0.0] = gain_prior_zeropoint_std
+    return ps

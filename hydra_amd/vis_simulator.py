@@ -420,3 +420,13 @@ def simulate_vis_per_alm(lmax, nside, ants, freqs, lsts, beams, polarized=False,
     vis[:, :, torch.as_tensor(bl_i, device=V.device).long(),
         torch.as_tensor(bl_j, device=V.device).long(), :] = tri.permute(1, 2, 0, 3)
     return ell, m, vis.cpu().numpy()
+
+
+def simulate_vis_per_region(lmax, nside, ants, freqs, lsts, beams, polarized=False, precision=2,
+                            latitude=DEFAULT_LATITUDE, use_feed="x", multiprocess=True,
+                            amplitude=1.0, logfile=None):
+    """The reference keeps a second copy of ``simulate_vis_per_alm`` under this name
+    (vis_simulator.py:739-906; it only adds ``multiprocess`` to the inner call): same result."""
+    return simulate_vis_per_alm(lmax, nside, ants, freqs, lsts, beams, polarized=polarized,
+                                precision=precision, latitude=latitude, use_feed=use_feed,
+                                multiprocess=multiprocess, amplitude=amplitude, logfile=logfile)

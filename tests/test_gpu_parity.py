@@ -445,6 +445,9 @@ def test_sh_response_operator_matches_oracle(hy, orc):
                                                          latitude=-0.5361913261514378)
     e4, m4, cube_r = orc.response.simulate_vis_per_alm(lmax, nside, ant_pos, freqs * 1e6, lsts, bo,
                                                        latitude=-0.5361913261514378)
+    e5, m5, cube5 = hy.vis_simulator.simulate_vis_per_region(lmax, nside, ant_pos, freqs * 1e6, lsts,
+                                                             bh, latitude=LAT)
+    assert np.array_equal(e5, e3) and np.array_equal(m5, m3) and np.array_equal(cube5, cube)
     assert cube.shape == cube_r.shape and operr(cube, cube_r) < OP_TOL
 
 

@@ -204,3 +204,25 @@ def test_radiometer_eq_matches_the_reference():
         got = sh_sampler.radiometer_eq(g[tag + "_autos"], ants, 10.7, 97.6e3, Nnights=3,
                                        include_autos=True)
         assert np.array_equal(got, g[tag + "_with_autos"])
+
+
+def test_padding_and_gain_prior_helpers_match_the_reference(tmp_path):
+    """utils.extend_coords_with_padding, gain_prior_pspec_sqrt and load_gain_model against the
+    reference's outputs (tests/golden/utils3.npz, made by make_golden_utils3.py), bit for bit."""
+    g = load_golden("utils3.npz")
+    freqs, lsts = g["freqs"], g["lsts"]
+    assert np.array_equal(utils.extend_coords_with_padding(freqs, pad=[2, 3]), g["pad_f"])
+    assert np.array_equal(utils.extend_coords_with_padding(lsts, pad=[0, 4]), g["pad_t"])
+    assert np.array_equal(utils.extend_coords_with_padding(lsts), g["pad_none"])
+    assert np.array_equal(utils.gain_prior_pspec_sqrt(lsts, freqs, 0.1), g["ps_flat"])
+    got = utils.gain_prior_pspec_sqrt(lsts, freqs, 0.1, gain_prior_sigma_frate=0.5,
+                                      gain_prior_sigma_delay=80.0, gain_prior_zeropoint_std=0.3,
+                                      frate0=0.1, delay0=-20.0)
+    assert np.array_equal(got, g["ps_taper"])
+    assert np.array_equal(utils.gain_prior_pspec_sqrt(lsts, freqs, 2.0, gain_prior_sigma_frate=1.5),
+                          g["ps_frate"])
+    path = str(tmp_path / "g.npy")
+    np.save(path, g["gain_model"])
+    assert np.array_equal(utils.load_gain_model(path, lst_pad=[1, 2], freq_pad=[3, 0]),
+                          g["gain_padded"])
+    assert np.array_equal(utils.load_gain_model(path), g["gain_plain"])
