@@ -25,9 +25,14 @@ namespace hydra {
 
 #ifdef HYDRA_GRAM_STAMPS
 // Diagnostic build only (make stamps): cycle shares of the fused kernel's phases, summed by
-// wave 0 of workgroup 0.  [0] LDS fill, [1] load issue, [2] MFMA burst, [3] VALU batch,
-// [4] k-steps, [5] shader cycles total, [6] 100 MHz ticks total.  Never built into the product.
+// wave 0 of workgroup 0.  [0] segment change (barrier wait + LDS fill), [5] shader cycles total,
+// [6] 100 MHz ticks total; with -DHYDRA_GRAM_STAMPS_INNER also [1] load issue, [2] MFMA burst,
+// [3] VALU batch, [4] k-steps -- those stamps wait for the LDS reads in flight and so change
+// what they measure; the per-wave timeline (g_trace) does not.  Never built into the product.
 __device__ unsigned long long g_stamps[8];
+// per-wave timeline of workgroup 0's third (f,t): [wave][barrier-1 arrival, after barrier 1,
+// DMA landed, after barrier 2, loop end]
+__device__ unsigned long long g_trace[8][8];
 #define STAMP(var)                                                                       \
   __builtin_amdgcn_sched_barrier(0);                                                     \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
@@ -98,20 +103,19 @@ struct Frag {
 // k, which cover the load latency, (3) one batch of VALU turning the loaded values into the
 // operands of step k+1.
 template <class P>
-__device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long long k_end,
-                                              f64x4 (&acc)[4][4], int kstride = 4) {
+__device__ __forceinline__ void mfma_pipeline(P& prod, int nsteps, f64x4 (&acc)[4][4]) {
   Frag cur;
-  prod.issue(k_begin);
+  prod.issue();
   prod.finish(cur);
-#ifdef HYDRA_GRAM_STAMPS
+#ifdef HYDRA_GRAM_STAMPS_INNER
   unsigned long long t0, t1, t2, t3, s_issue = 0, s_mfma = 0, s_valu = 0, s_steps = 0;
 #endif
-  for (long long k0 = k_begin; k0 < k_end; k0 += kstride) {
-#ifdef HYDRA_GRAM_STAMPS
+  for (int n = 0; n < nsteps; ++n) {
+#ifdef HYDRA_GRAM_STAMPS_INNER
     STAMP(t0)
 #endif
-    prod.issue(k0 + kstride);  // past the end: the producer clamps the row and yields zeros
-#ifdef HYDRA_GRAM_STAMPS
+    prod.issue();  // past the end: the producer clamps the row and yields zeros
+#ifdef HYDRA_GRAM_STAMPS_INNER
     STAMP(t1)
 #endif
     __builtin_amdgcn_sched_barrier(0);
@@ -123,17 +127,17 @@ __device__ __forceinline__ void mfma_pipeline(P& prod, long long k_begin, long l
       for (int ni = 0; ni < 4; ++ni) acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
     }
     __builtin_amdgcn_sched_barrier(0);
-#ifdef HYDRA_GRAM_STAMPS
+#ifdef HYDRA_GRAM_STAMPS_INNER
     STAMP(t2)
 #endif
     prod.finish(cur);
     __builtin_amdgcn_sched_barrier(0);
-#ifdef HYDRA_GRAM_STAMPS
+#ifdef HYDRA_GRAM_STAMPS_INNER
     STAMP(t3)
     s_issue += t1 - t0; s_mfma += t2 - t1; s_valu += t3 - t2; s_steps += 1;
 #endif
   }
-#ifdef HYDRA_GRAM_STAMPS
+#ifdef HYDRA_GRAM_STAMPS_INNER
   if (blockIdx.x == 0 && threadIdx.x == 0) {
     g_stamps[1] += s_issue; g_stamps[2] += s_mfma; g_stamps[3] += s_valu; g_stamps[4] += s_steps;
   }
@@ -342,35 +346,75 @@ static void gram_plan(long long nunits, int ns, int* ntiles, int* nsplit, long l
 
 // ------------------------------------------------------------------ fused (factored) form
 
-// w_t[ft][b] = inv_noise[b][ft] (or 1): contiguous per (f,t) slice for LDS staging
+// Row factor of every baseline row and (f,t) sample, in the row order of the segment table:
+//   out[ft][row] = inv_noise[b][ft] |g_i|^2 |g_j|^2 .
+// Only |c_r|^2 of the reference's complex row factor c_r = g_i conj(g_j) sqrt(w) survives in
+// Re(conj(R'_r,s) R'_r,s'), so the gains never touch the voltages: the Gram kernel copies raw V
+// into LDS by DMA and multiplies its A operands by this one real number per row.
 __global__ void __launch_bounds__(256)
-sqrtw_transpose_kernel(const double* __restrict__ w, int nbl, int nft, double* __restrict__ out) {
-  size_t n = (size_t)nbl * nft;
+row_weights_kernel(const double* __restrict__ w, const f64x2* __restrict__ gains,
+                   const int32_t* __restrict__ seg, const int32_t* __restrict__ rowtab, int nbl,
+                   int nft, double* __restrict__ out) {
+  const int32_t* sd = seg + 6 * blockIdx.y;
+  const int i0 = sd[0], ni = sd[1], j0 = sd[2], row0 = sd[4], nrows = sd[5];
+  size_t n = (size_t)nrows * nft;
   for (size_t o = blockIdx.x * (size_t)blockDim.x + threadIdx.x; o < n;
        o += (size_t)gridDim.x * blockDim.x) {
-    size_t ft = o / nbl, b = o % nbl;
-    out[o] = w ? w[b * (size_t)nft + ft] : 1.0;
+    int ft = (int)(o / nrows), r = (int)(o % nrows);
+    const int32_t* rt = rowtab + 3 * (size_t)(row0 + r);
+    double v = w ? w[(size_t)rt[2] * nft + ft] : 1.0;
+    if (gains) {
+      int ai = rt[0] < ni ? i0 + rt[0] : j0 + (rt[0] - ni);
+      int aj = rt[1] < ni ? i0 + rt[1] : j0 + (rt[1] - ni);
+      f64x2 gi = gains[(size_t)ai * nft + ft], gj = gains[(size_t)aj * nft + ft];
+      v *= (gi.x * gi.x + gi.y * gi.y) * (gj.x * gj.x + gj.y * gj.y);
+    }
+    out[(size_t)ft * nbl + row0 + r] = v;
   }
 }
 
+// Which k-steps (groups of 4 baseline rows) a wave group takes.  One group: all of them.  Two
+// groups share a SIMD pairwise, and the matrix pipe serves the older wave (group 0) first: the
+// younger only gets the gaps the older leaves while it reads LDS and forms operands.  With
+// alternate k-steps group 0 finished a segment 20 % of the segment's time before group 1 and
+// idled at the barrier (per-wave timeline of tools/gram_stamps.py, config 2: loops of 320 k and
+// 400 k cycles).  The split follows the measured rates instead: of every 5 k-steps group 0 takes
+// numbers 0, 2, 4 and group 1 takes 1, 3.  The assignment is static, so the summation order --
+// and with it every bit of the result -- stays the same from run to run.
+template <int NG>
+struct KSplit {
+  __device__ static __forceinline__ int step(int grp, int n) {          // n-th k-step of a group
+    if (NG == 1) return n;
+    return grp == 0 ? 5 * (n / 3) + 2 * (n % 3) : 5 * (n / 2) + 1 + 2 * (n % 2);
+  }
+  __device__ static __forceinline__ int count(int grp, int nk) {        // of nk k-steps in all
+    if (NG == 1) return nk;
+    int rem = nk % 5;
+    return grp == 0 ? 3 * (nk / 5) + (rem + 1) / 2 : 2 * (nk / 5) + rem / 2;
+  }
+};
+
+template <int NG>
 struct FusedProducer {
   const f64x2* s_u;
   const double* s_w;
   const uint32_t* s_info;
-  int nrows, kr, offA, offB, kstride;
+  int nrows, kr, offA, offB, grp;
+  int n_next;           // ordinal (within the group) of the k-step whose row info is fetched next
   uint32_t info_next;   // packed LDS rows of the step after the one being issued
   double w_next, w;
   f64x2 ai[4], aj[4], bi[4], bj[4];
 
-  __device__ __forceinline__ void prefetch_info(int k0) {
-    int r = k0 + kr;
+  __device__ __forceinline__ void prefetch_info() {
+    int r = 4 * KSplit<NG>::step(grp, n_next) + kr;
+    ++n_next;
     bool valid = r < nrows;
     info_next = s_info[valid ? r : 0];
     w_next = valid ? s_w[r] : 0.0;
   }
-  __device__ __forceinline__ void start(int k0) { prefetch_info(k0); }
+  __device__ __forceinline__ void start() { n_next = 0; prefetch_info(); }
   // LDS reads of the k-step whose row info was prefetched; then prefetch the next step's info
-  __device__ __forceinline__ void issue(long long k0) {
+  __device__ __forceinline__ void issue() {
     const f64x2* pi = s_u + (info_next & 0xffffu) * 256;
     const f64x2* pj = s_u + (info_next >> 16) * 256;
     w = w_next;
@@ -379,10 +423,10 @@ struct FusedProducer {
       ai[g] = pi[offA + g * 16]; aj[g] = pj[offA + g * 16];
       bi[g] = pi[offB + g * 16]; bj[g] = pj[offB + g * 16];
     }
-    prefetch_info((int)k0 + kstride);
+    prefetch_info();
   }
-  // R'[r,s] = conj(u_i,s) u_j,s with u_a = conj(g_a) v_a staged in LDS; the noise weight w_r
-  // goes wholly on the A side (sum_r w_r t_r[s] t_r[s'] needs it once)
+  // P[r,s] = conj(v_i,s) v_j,s from the voltages staged in LDS; the real row factor
+  // w_r |g_i g_j|^2 goes wholly on the A side (sum_r c_r P_r[s] P_r[s'] needs it once)
   __device__ __forceinline__ void finish(Frag& f) const {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -395,7 +439,7 @@ struct FusedProducer {
   }
 };
 
-// LDS: u[nrows_lds][256] complex (cols 0..127: A side = row-tile sources; 128..255: B side)
+// LDS: v[nrows_lds][256] complex (cols 0..127: A side = row-tile sources; 128..255: B side)
 //      info[max_rows] uint32 (ldsrow_i | ldsrow_j << 16), sw[max_rows] f64
 // The register cap of 256 (2 waves per SIMD) makes hipcc keep the MFMA accumulators in
 // ArchVGPRs: on gfx950 an f64 MFMA whose C/D operand sits in AGPRs issues at about half rate
@@ -406,10 +450,20 @@ struct FusedProducer {
 // voltages and take alternate k-steps of the same 128x128 tile, so one wave's LDS reads,
 // waits and VALU batch run under the other's MFMA burst.  Group 1 hands its accumulators to
 // group 0 through LDS at the end (fixed order: group 0 + group 1).
+//
+// Staging.  Between two segments the matrix pipe has nothing to do (the LDS rows are being
+// replaced), so the fill must be ONE memory round trip: every wave copies its quarter of the
+// 256 columns (64 lanes x 16 B = 1 KiB per instruction) of its antennas straight from V by
+// LDS-DMA, all instructions in flight together, no registers, no VALU; the row factors come in
+// row order from row_weights_kernel, the packed LDS rows do not depend on (f,t) and are written
+// once when there is a single segment.  (The first version multiplied the gains in while
+// staging through registers, 8 loads at a time, and chased rowtab -> baseline -> weight: 5-7
+// dependent round trips, 19.5 % of the kernel at config 2 by tools/gram_stamps.py.)
+// Columns past ns are clamped: their products land in entries the slab sum never reads.
 template <int NG>
 __global__ void __launch_bounds__(256 * NG, 2 / NG)
 gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
-                  const f64x2* __restrict__ gains, const double* __restrict__ sqrtw_t, int nbl,
+                  const double* __restrict__ wrow, int nbl,
                   const int32_t* __restrict__ seg, int nseg, const int32_t* __restrict__ rowtab,
                   int max_lds_rows, int max_seg_rows, int ntiles, int ft_per_split,
                   double* __restrict__ slabs) {
@@ -438,10 +492,14 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = f64x4{0.0, 0.0, 0.0, 0.0};
 
-  // column this thread stages into LDS (each group stages every NG-th antenna)
-  int scid = tid & 255;
-  int scol = (scid < 128) ? ti * TS + scid : tj * TS + (scid - 128);
-  bool scol_ok = scol < ns;
+  // this wave's quarter of the staged columns, and where it lands in an LDS row
+  const int swave = __builtin_amdgcn_readfirstlane(tid >> 6);        // 0 .. 4 NG - 1
+  const int sq = swave & 3;
+  const int scol = (sq < 2 ? ti * TS + sq * 64 : tj * TS + (sq - 2) * 64) + lane;
+  const unsigned svoff = (unsigned)min(scol, ns - 1) * 16u;
+  const unsigned lds_q = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)(s_u + sq * 64));
+  const int scid = tid & 255;
   const int kr = lane >> 4;
   const int offA = wr * 64 + (lane & 15);
   const int offB = 128 + wc * 64 + (lane & 15);
@@ -453,42 +511,51 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
       int i0 = sd[0], ni = sd[1], j0 = sd[2], nj = sd[3], row0 = sd[4], nrows = sd[5];
       int nload = (j0 == i0) ? ni : ni + nj;
 #ifdef HYDRA_GRAM_STAMPS
-      unsigned long long f0, f1;
+      unsigned long long f0, f1, e1, e2, e5;
       STAMP(f0)
 #endif
       __syncthreads();  // previous segment fully consumed
-      // stage u_a = conj(g_a) v_a: 8 antennas per pass so 8 global loads are in flight per lane
-      for (int a0 = grp; a0 < nload; a0 += 8 * NG) {
-        f64x2 u[8], g[8];
-#pragma unroll
-        for (int q = 0; q < 8; ++q) {
-          int a = a0 + q * NG;
-          int ant = (a < ni) ? i0 + a : j0 + (a - ni);
-          bool ok = scol_ok && a < nload;
-          u[q] = ok ? vft[(size_t)ant * ns + scol] : f64x2{0.0, 0.0};
-          g[q] = (ok && gains) ? gains[(size_t)ant * nft + ft] : f64x2{1.0, 0.0};
+#ifdef HYDRA_GRAM_STAMPS
+      STAMP(e1)
+#endif
+      for (int a = swave >> 2; a < nload; a += NG) {
+        int ant = (a < ni) ? i0 + a : j0 + (a - ni);
+        const char* src = reinterpret_cast<const char*>(vft + (size_t)ant * ns);   // uniform
+        const unsigned dst = lds_q + (unsigned)a * 4096u;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(svoff), "s"(src) : "memory");
+      }
+      if (nseg > 1 || ft == ft_begin) {
+        for (int r = tid; r < nrows; r += NTHREADS) {
+          const int32_t* rt = rowtab + 3 * (size_t)(row0 + r);
+          s_info[r] = (uint32_t)rt[0] | ((uint32_t)rt[1] << 16);
         }
-#pragma unroll
-        for (int q = 0; q < 8; ++q)
-          if (a0 + q * NG < nload) s_u[(a0 + q * NG) * 256 + scid] = cmul_conj(g[q], u[q]);
       }
-      for (int r = tid; r < nrows; r += NTHREADS) {
-        const int32_t* rt = rowtab + 3 * (size_t)(row0 + r);
-        s_info[r] = (uint32_t)rt[0] | ((uint32_t)rt[1] << 16);
-        s_sw[r] = sqrtw_t[(size_t)ft * nbl + rt[2]];
-      }
+      const double* wft = wrow + (size_t)ft * nbl + row0;
+      for (int r = tid; r < nrows; r += NTHREADS) s_sw[r] = wft[r];
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // the DMA is invisible to the compiler
+#ifdef HYDRA_GRAM_STAMPS
+      STAMP(e2)
+#endif
       __syncthreads();
 #ifdef HYDRA_GRAM_STAMPS
       STAMP(f1)
       if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[0] += f1 - f0;
 #endif
 
-      FusedProducer prod;
+      FusedProducer<NG> prod;
       prod.s_u = s_u; prod.s_w = s_sw; prod.s_info = s_info;
       prod.nrows = nrows; prod.kr = kr; prod.offA = offA; prod.offB = offB;
-      prod.kstride = 4 * NG;
-      prod.start(4 * grp);
-      mfma_pipeline(prod, 4 * grp, nrows, acc, 4 * NG);
+      prod.grp = swave >> 2;
+      prod.start();
+      mfma_pipeline(prod, KSplit<NG>::count(swave >> 2, (nrows + 3) / 4), acc);
+#ifdef HYDRA_GRAM_STAMPS
+      STAMP(e5)
+      if (blockIdx.x == 0 && lane == 0 && ft == ft_begin + 2 && sg == 0) {
+        g_trace[swave][0] = f0; g_trace[swave][1] = e1; g_trace[swave][2] = e2;
+        g_trace[swave][3] = f1; g_trace[swave][4] = e5;
+      }
+#endif
     }
   }
   if (NG == 2) {
@@ -555,34 +622,55 @@ constexpr int UCH = HYDRA_K3_UCH;  // antennas per LDS buffer (k-steps of 4)
 //   sum_a q_a,s q_a,s' = (sum_a f_a^4) p_s p_s',  p_s = |v_0,s|^2,
 // and row `nant` carries (sqrt(sum_a f_a^4) p_s, 0): the kernel subtracts that rank-1 term with
 // one MFMA per block and (f,t) instead of one per k-step.
+// The factors are formed once per (f,t) and antenna (ufactor_kernel: two square roots each) and
+// the scaling pass only streams: with the square roots inside it, recomputed for every source,
+// the pass took 6.4 ms at config 2 -- 5 % of a sample -- for 3.1 GB of traffic.
 __global__ void __launch_bounds__(256)
-uscale_kernel(const f64x2* __restrict__ V, const f64x2* __restrict__ gains,
-              const double* __restrict__ wft, int nft, int nant, int nantp, int ns, int same_beam,
-              f64x2* __restrict__ U) {
+ufactor_kernel(const f64x2* __restrict__ gains, const double* __restrict__ wft, int nft, int nant,
+               int fstride, double* __restrict__ f) {
+  int ft = blockIdx.x * blockDim.x + threadIdx.x;
+  if (ft >= nft) return;
+  double w4 = wft ? sqrt(sqrt(wft[ft])) : 1.0;
+  double c4 = 0.0;
+  for (int a = 0; a < nant; ++a) {
+    double fa = w4;
+    if (gains) {
+      f64x2 g = gains[(size_t)a * nft + ft];
+      fa *= sqrt(g.x * g.x + g.y * g.y);
+    }
+    f[(size_t)ft * fstride + a] = fa;
+    double f2 = fa * fa;
+    c4 += f2 * f2;
+  }
+  f[(size_t)ft * fstride + nant] = sqrt(c4);
+}
+
+__global__ void __launch_bounds__(256)
+uscale_kernel(const f64x2* __restrict__ V, const double* __restrict__ f, int fstride, int nft,
+              int nant, int nantp, int ns, int same_beam, f64x2* __restrict__ U) {
   int s = blockIdx.x * blockDim.x + threadIdx.x;
   if (s >= ns) return;
   for (int ft = blockIdx.y; ft < nft; ft += gridDim.y) {   // grid.y is capped at 65535
-  double w4 = wft ? sqrt(sqrt(wft[ft])) : 1.0;
-  double c4 = 0.0;
-  f64x2 v0 = {0.0, 0.0};
-  for (int a = 0; a < nantp; ++a) {
-    f64x2 u = {0.0, 0.0};
-    if (a < nant) {
-      double f = w4;
-      if (gains) {
-        f64x2 g = gains[(size_t)a * nft + ft];
-        f *= sqrt(g.x * g.x + g.y * g.y);
-      }
-      f64x2 v = V[((size_t)ft * nant + a) * ns + s];
-      if (a == 0) v0 = v;
-      u = f64x2{v.x * f, v.y * f};
-      double f2 = f * f;
-      c4 += f2 * f2;
-    } else if (same_beam && a == nant) {
-      u = f64x2{sqrt(c4) * (v0.x * v0.x + v0.y * v0.y), 0.0};
+    const double* fr = f + (size_t)ft * fstride;           // uniform: scalar loads
+    const f64x2* vp = V + (size_t)ft * nant * ns + s;
+    f64x2* up = U + (size_t)ft * nantp * ns + s;
+    const f64x2 v0 = vp[0];
+    for (int a0 = 0; a0 < nant; a0 += 8) {                 // 8 loads in flight per lane
+      f64x2 v[8];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (a0 + q < nant) v[q] = vp[(size_t)(a0 + q) * ns];
+#pragma unroll
+      for (int q = 0; q < 8; ++q)
+        if (a0 + q < nant) {
+          double fa = fr[a0 + q];
+          up[(size_t)(a0 + q) * ns] = f64x2{v[q].x * fa, v[q].y * fa};
+        }
     }
-    U[((size_t)ft * nantp + a) * ns + s] = u;
-  }
+    for (int a = nant; a < nantp; ++a)
+      up[(size_t)a * ns] = (same_beam && a == nant)
+                               ? f64x2{fr[nant] * (v0.x * v0.x + v0.y * v0.y), 0.0}
+                               : f64x2{0.0, 0.0};
   }
 }
 
@@ -1057,6 +1145,9 @@ static void k3_plan(long long nft, int ns, int* ntiles, int* nsplit, long long* 
 using namespace hydra;
 
 #ifdef HYDRA_GRAM_STAMPS
+extern "C" int hydra_debug_trace(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_trace), sizeof(g_trace)) == hipSuccess ? 0 : -3;
+}
 extern "C" int hydra_debug_stamps(unsigned long long* out_host, int reset) {
   if (hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_stamps), sizeof(g_stamps)) != hipSuccess) return -3;
   if (reset) {
@@ -1221,8 +1312,12 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
   size_t slab_bytes = align_up((size_t)nsplit * ntiles * TILE_ELEMS * sizeof(double), 256);
   double* sqrtw_t = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + slab_bytes);
   hipStream_t st = as_stream(stream);
-  sqrtw_transpose_kernel<<<2048, 256, 0, st>>>(inv_noise, nbl, nft, sqrtw_t);
-  HYDRA_CHECK_LAUNCH("hydra_gram_fused(sqrtw)");
+  {
+    int gx = (int)std::min<long long>(((long long)max_seg_rows * nft + 255) / 256, 2048);
+    row_weights_kernel<<<dim3(gx, nseg), 256, 0, st>>>(
+        inv_noise, reinterpret_cast<const f64x2*>(gains), seg, rowtab, nbl, nft, sqrtw_t);
+  }
+  HYDRA_CHECK_LAUNCH("hydra_gram_fused(row weights)");
   // two wave groups per workgroup when LDS leaves room for a single workgroup per CU
   bool two_groups = lds > 80 * 1024;
   if (two_groups) lds = std::max<size_t>(lds, (size_t)TILE_ELEMS * sizeof(double));
@@ -1235,12 +1330,12 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
   profile_record(0, st);
   if (two_groups)
     gram_fused_kernel<2><<<ntiles * nsplit, 512, lds, st>>>(
-        reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
-        sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
+        reinterpret_cast<const f64x2*>(V), nft, nant, ns, sqrtw_t, nbl, seg, nseg, rowtab,
+        max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
   else
     gram_fused_kernel<1><<<ntiles * nsplit, 256, lds, st>>>(
-        reinterpret_cast<const f64x2*>(V), nft, nant, ns, reinterpret_cast<const f64x2*>(gains),
-        sqrtw_t, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
+        reinterpret_cast<const f64x2*>(V), nft, nant, ns, sqrtw_t, nbl, seg, nseg, rowtab,
+        max_lds_rows, max_seg_rows, ntiles, (int)per, slabs);
   profile_record(1, st);
   HYDRA_CHECK_LAUNCH("hydra_gram_fused");
   gram_finish_kernel<<<ntiles, 256, 0, st>>>(slabs, nsplit, ntiles, ns, prior_std, add_diag, G);
@@ -1256,8 +1351,9 @@ size_t hydra_gram_uniform_workspace_bytes(int nf, int nt, int nant, int ns) {
   k3_plan((long long)nf * nt, ns, &ntiles, &nsplit, &per);
   size_t slabs = align_up((size_t)nsplit * ntiles * K3_TILE * sizeof(double), 256);
   int nantp = (nant + 1 + 3) / 4 * 4;   // room for the same-beam row
+  size_t ftab = align_up((size_t)nf * nt * (nant + 1) * sizeof(double), 256);   // scale factors
   // + UCH scratch rows: the staging of the last (partial) antenna buffer reads a whole buffer
-  return slabs + ((size_t)nf * nt * nantp + UCH) * ns * 16;
+  return slabs + ftab + ((size_t)nf * nt * nantp + UCH) * ns * 16;
 }
 
 int hydra_noise_uniformity(const double* inv_noise, int nbl, int nf, int nt, double* w_ft,
@@ -1293,12 +1389,16 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   k3_plan(nft, ns, &ntiles, &nsplit, &per);
   double* slabs = static_cast<double*>(workspace);
   size_t slab_bytes = align_up((size_t)nsplit * ntiles * K3_TILE * sizeof(double), 256);
-  f64x2* U = reinterpret_cast<f64x2*>(static_cast<unsigned char*>(workspace) + slab_bytes);
+  double* ftab = reinterpret_cast<double*>(static_cast<unsigned char*>(workspace) + slab_bytes);
+  size_t ftab_bytes = align_up((size_t)nft * (nant + 1) * sizeof(double), 256);
+  f64x2* U = reinterpret_cast<f64x2*>(static_cast<unsigned char*>(workspace) + slab_bytes + ftab_bytes);
   hipStream_t st = as_stream(stream);
+  ufactor_kernel<<<(nft + 255) / 256, 256, 0, st>>>(reinterpret_cast<const f64x2*>(gains), w_ft, nft,
+                                                    nant, nant + 1, ftab);
+  HYDRA_CHECK_LAUNCH("hydra_gram_uniform(factors)");
   dim3 ugrid((ns + 255) / 256, std::min(nft, 65535));
-  uscale_kernel<<<ugrid, 256, 0, st>>>(reinterpret_cast<const f64x2*>(V),
-                                       reinterpret_cast<const f64x2*>(gains), w_ft, nft, nant, nantp,
-                                       ns, same_beam, U);
+  uscale_kernel<<<ugrid, 256, 0, st>>>(reinterpret_cast<const f64x2*>(V), ftab, nant + 1, nft, nant,
+                                       nantp, ns, same_beam, U);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform(scale)");
   size_t lds = (size_t)2 * UCH * K3_W * 16;
   profile_record(0, st);
