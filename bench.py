@@ -569,14 +569,19 @@ def main_gain(args, comm, rank, world, dev):
         torch.cuda.synchronize()
 
     def one_sample(k):
-        ggv_k = hy.utils.apply_gains(model, gains, ants, antpairs, inline=False)
-        resid = data - ggv_k
         om_y = torch.randn((nant, nmodes), dtype=torch.complex128, device="cpu",
                            generator=torch.Generator().manual_seed(1000 + k)).numpy()
         om_r = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
-        b = gs.construct_rhs_mpi(comm, resid, inv_noise, ps, A_real, A_imag, ggv_k, Fb,
-                                 omega_y=om_y, omega_r=om_r)
-        op = gs.GainOperator(inv_noise, ps, A_real, A_imag, ggv_k, Fb)
+        if args.gain_unfused:
+            ggv_k = hy.utils.apply_gains(model, gains, ants, antpairs, inline=False)
+            resid = data - ggv_k
+            b = gs.construct_rhs_mpi(comm, resid, inv_noise, ps, A_real, A_imag, ggv_k, Fb,
+                                     omega_y=om_y, omega_r=om_r)
+            op = gs.GainOperator(inv_noise, ps, A_real, A_imag, ggv_k, Fb)
+        else:
+            # the same four steps in one pass over the visibilities (gain_sampler.prepare_sample)
+            b, op = gs.prepare_sample(comm, data, model, gains, inv_noise, ps, A_real, A_imag, Fb,
+                                      omega_y=om_y, omega_r=om_r)
         if comm is None:
             lin = op.apply
         else:
@@ -637,6 +642,29 @@ def main_gain(args, comm, rank, world, dev):
     torch.cuda.synchronize()
     pair_ms = e0.elapsed_time(e1) / 20
     pair_kernel = "gain_pairs_stream_kernel" if op.stream else "gain_pairs_tiled_kernel"
+    # the one-pass preparation kernel alone (model, data, weights, omega read once; W written once)
+    prep = None
+    if not args.gain_unfused and op.stream and getattr(op, "_model", None) is not None:
+        om_r = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+        sw1, yy1 = torch.empty_like(op.sw), torch.empty((nant, nft_loc), dtype=torch.complex128, device=dev)
+        idx = gs._index_of(A_real, A_imag)
+
+        def prep_once():
+            dv.call("hydra_gain_prepare_stream", dv.ptr(data), dv.ptr(model), dv.ptr(gains),
+                    dv.ptr(inv_noise), dv.ptr(om_r), nbl, nant, nft_loc, dv.ptr(idx.pair_dev()),
+                    dv.ptr(op.Wt), dv.ptr(sw1), dv.ptr(yy1), dv.stream_ptr())
+        prep_once()
+        e0.record()
+        for _ in range(5):
+            prep_once()
+        e1.record()
+        torch.cuda.synchronize()
+        prep_ms = e0.elapsed_time(e1) / 5
+        prep_bytes = 64.0 * m_loc            # 16 + 16 + 8 + 16 read, 8 written per visibility
+        prep = {"kernel": "gain_prepare_stream_kernel", "ms_per_launch": prep_ms,
+                "bytes_per_launch": prep_bytes, "achieved": prep_bytes / (prep_ms * 1e-3) / 1e9,
+                "peak": 8000.0, "unit": "GB/s", "frac": prep_bytes / (prep_ms * 1e-3) / 1e9 / 8000.0}
+        del om_r, sw1, yy1
     if rank != 0:
         return
     lhs = x + op.local(x) if comm is None else None
@@ -669,8 +697,12 @@ def main_gain(args, comm, rank, world, dev):
             "note": "8 M bytes: the fused real weight |g g* V|^2 N^-1 of every visibility once",
         },
         "operator_application_ms": one_ms,
+        "prepare_pass": prep,
         "cpu_baseline": None,
     }
+    out["config"]["preparation"] = ("separate passes (apply_gains, residual, construct_rhs_mpi, "
+                                    "GainOperator)" if args.gain_unfused else
+                                    "one pass over the visibilities (gain_sampler.prepare_sample)")
     if not args.no_cpu and world == 1:     # CPU leg: single-GPU runs only
         out["cpu_baseline"] = gain_cpu_baseline(ants, antpairs, Fb_all, nf, nt, iters)
     print(json.dumps(out))
@@ -967,6 +999,9 @@ def main():
                     help="fraction of (baseline, freq, time) samples flagged (inverse noise variance "
                          "0) at random, plus one dead baseline: the closed-form Gram then takes its "
                          "flagged-row correction (ptsrc configs)")
+    ap.add_argument("--gain-unfused", action="store_true",
+                    help="gain head: run apply_gains / residual / construct_rhs_mpi / GainOperator "
+                         "as separate passes instead of gain_sampler.prepare_sample")
     ap.add_argument("--no-general", action="store_true",
                     help="skip the extra launches of the general Gram kernel after the timed region")
     ap.add_argument("--shard", default=None, choices=["freq", "baseline"],

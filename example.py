@@ -270,17 +270,18 @@ def main(argv=None, on_head=None):
 
         if args.sample_gains:                             # (A) example.py:673-745
             t0 = time.time()
-            ggv = hydra.apply_gains(current_model, gains_chunk, ants, antpairs, inline=False)
-            resid = data_chunk - ggv
-            notify("gains", n, resid=resid, model_vis=ggv, inv_noise_var=inv_noise_var_chunk,
-                   pspec_sqrt=gain_pspec_sqrt, Fbasis=Fbasis_h, seed=100000 * myid + n,
-                   ants=ants, antpairs=antpairs)
-            bgain = hydra.gain_sampler.construct_rhs_mpi(
-                comm=comm, resid=resid, inv_noise_var=inv_noise_var_chunk,
-                pspec_sqrt=gain_pspec_sqrt_d, A_real=A_real, A_imag=A_imag, model_vis=ggv,
-                Fbasis=Fbasis, realisation=True, seed=100000 * myid + n)
-            op = hydra.gain_sampler.GainOperator(inv_noise_var_chunk, gain_pspec_sqrt_d, A_real,
-                                                 A_imag, ggv, Fbasis)
+            if on_head is not None:
+                ggv = hydra.apply_gains(current_model, gains_chunk, ants, antpairs, inline=False)
+                notify("gains", n, resid=data_chunk - ggv, model_vis=ggv,
+                       inv_noise_var=inv_noise_var_chunk, pspec_sqrt=gain_pspec_sqrt,
+                       Fbasis=Fbasis_h, seed=100000 * myid + n, ants=ants, antpairs=antpairs)
+                del ggv
+            # apply_gains, the residual, construct_rhs_mpi and the operator weights
+            # (example.py:690-745) in one pass over the visibilities
+            bgain, op = hydra.gain_sampler.prepare_sample(
+                comm, data_chunk, current_model, gains_chunk, inv_noise_var_chunk,
+                gain_pspec_sqrt_d, A_real, A_imag, Fbasis, realisation=True,
+                seed=100000 * myid + n)
             if comm is None:
                 lin = op.apply
             else:

@@ -287,6 +287,156 @@ gain_weights_stream_kernel(const f64x2* __restrict__ mv, const double* __restric
   }
 }
 
+// One pass over the visibilities for everything a gain GCR sample needs from them.  Per baseline
+// b = (a, o), a < o, and (f,t) sample, with v = g_a conj(g_o) m_b the gain-applied model
+// (utils.py:63-110), r = d_b - v the residual (example.py:690-700) and w the inverse noise
+// variance:
+//   W_b   = |v|^2 w                                   operator weight, gain_sampler.py:278-284
+//   z_b   = r w + omega_b sqrt(w)                     gain_sampler.py:201-204
+//   p_b   = conj(v) z_b                               A^H z, gain_sampler.py:109-142:
+//   yy[a] += p_b,  yy[o] += conj(p_b),  sw[a] += W_b,  sw[o] += W_b
+// W goes straight into the stream layout of the pair kernel (header and slots identical to
+// gain_weights_stream_kernel's), yy and sw -- the antenna-space right-hand side before the basis
+// projection and the operator's diagonal term -- leave as (Nant, Nft) arrays.  The unfused sequence
+// (apply_gains, a subtraction, rhs_rows, proj_conj, weights_stream, one pair-kernel application to
+// ones) moves 55 GB at config 4; this pass reads model, data, weights and omega once and writes W
+// once: 14.3 GB.
+//
+// A workgroup owns FT consecutive samples and all antennas, like the pair kernel: gains, yy and sw
+// of its samples live in LDS.  Its two halves (256 threads each) take alternate sub-tiles of a
+// sweep; thread (ft, c) of a half owns column antenna o of its sub-tile -- it adds the column sums
+// of the 8 rows to yy[o], sw[o] (one owner per entry) -- and keeps the 8 row sums in registers
+// across the sweep; at the end of the sweep they are reduced over the lanes of equal ft (xor
+// shuffles), then over the 8 waves through LDS in wave order.  Fixed summation order, no atomics.
+// Every thread has its 8 index loads, then its 32 data loads (one 128-byte line per 8 lanes and
+// array at FT = 8) in flight together.
+constexpr int GP_THREADS = 512;
+
+template <int FT>
+__global__ void __launch_bounds__(GP_THREADS)
+gain_prepare_stream_kernel(const f64x2* __restrict__ data, const f64x2* __restrict__ model,
+                           const f64x2* __restrict__ gains, const double* __restrict__ w,
+                           const f64x2* __restrict__ om, const int32_t* __restrict__ pairb,
+                           int nant, int nft, long long header, long long chunk_len,
+                           double* __restrict__ Wt, double* __restrict__ sw_out,
+                           f64x2* __restrict__ yy) {
+  using G = GainStream<FT>;
+  constexpr int COLS = G::COLS;
+  extern __shared__ __align__(16) unsigned char smem[];
+  const int nantp = ((nant + 7) & ~7) + COLS + 8;
+  f64x2* s_g = reinterpret_cast<f64x2*>(smem);                 // [nantp][FT] gains
+  f64x2* s_t = s_g + (size_t)nantp * FT;                       // [nantp][FT] yy
+  double* s_sw = reinterpret_cast<double*>(s_t + (size_t)nantp * FT);   // [nantp][FT]
+  double* s_red = s_sw + (size_t)nantp * FT;                   // [8 waves][8 rows][FT][3]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int half = wave >> 2, t = tid & 255;
+  const int cft = t % FT, cc = t / FT;
+  const int chunk = blockIdx.x, ft0 = chunk * FT, ft = ft0 + cft;
+  const bool ftok = ft < nft;
+
+  for (int e = tid; e < nantp * FT; e += GP_THREADS) {
+    const int a = e / FT, f = ft0 + (e - a * FT);
+    s_g[e] = (a < nant && f < nft) ? gains[(size_t)a * nft + f] : f64x2{0.0, 0.0};
+    s_t[e] = f64x2{0.0, 0.0};
+    s_sw[e] = 0.0;
+  }
+  __syncthreads();
+
+  double* wchunk = Wt + header + (long long)chunk * chunk_len;
+  const int nsweeps = gs_nsweeps(nant);
+  for (int A = 0; A < nsweeps; ++A) {
+    const int L = nant - 1 - 8 * A, ntl = (L + COLS - 1) / COLS;
+    f64x2 ga[8], racc[8];
+    double rsw[8];
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      ga[r] = s_g[(size_t)(8 * A + r) * FT + cft];
+      racc[r] = f64x2{0.0, 0.0};
+      rsw[r] = 0.0;
+    }
+    for (int k = half; k < ntl; k += 2) {
+      const int nc = min(COLS, L - k * COLS);
+      if (cc < nc) {
+        const int o = 8 * A + 1 + k * COLS + cc;
+        int b[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const int a = 8 * A + r;
+          b[r] = (a < o && a < nant) ? pairb[(size_t)a * nant + o] : -1;
+        }
+        f64x2 m[8], d[8], q[8];
+        double ww[8];
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const size_t idx = (b[r] >= 0 && ftok) ? (size_t)b[r] * nft + ft : 0;
+          m[r] = model[idx];
+          d[r] = data[idx];
+          ww[r] = w ? w[idx] : 1.0;
+          q[r] = om ? om[idx] : f64x2{0.0, 0.0};
+        }
+        const f64x2 go = s_g[(size_t)o * FT + cft];
+        f64x2 tcol = {0.0, 0.0};
+        double swc = 0.0;
+        double* wo = wchunk + gs_sweep_base(A, nant, FT) + (long long)k * 8 * COLS * FT + cc * FT + cft;
+#pragma unroll
+        for (int r = 0; r < 8; ++r) {
+          const bool valid = b[r] >= 0 && ftok;
+          const f64x2 v = cmul(cmul_conj(go, ga[r]), m[r]);              // g_a conj(g_o) m
+          const double W = valid ? (v.x * v.x + v.y * v.y) * ww[r] : 0.0;
+          const double rt = sqrt(ww[r]);
+          const f64x2 z = {(d[r].x - v.x) * ww[r] + q[r].x * rt, (d[r].y - v.y) * ww[r] + q[r].y * rt};
+          f64x2 p = cmul_conj(v, z);
+          if (!valid) p = f64x2{0.0, 0.0};
+          racc[r].x += p.x; racc[r].y += p.y; rsw[r] += W;
+          tcol.x += p.x; tcol.y -= p.y; swc += W;
+          wo[(size_t)r * nc * FT] = W;
+        }
+        f64x2* tp = s_t + (size_t)o * FT + cft;
+        const f64x2 told = *tp;
+        *tp = f64x2{told.x + tcol.x, told.y + tcol.y};
+        s_sw[(size_t)o * FT + cft] += swc;
+      }
+    }
+    // row sums of the sweep: lanes of equal ft, then the 8 waves in order
+#pragma unroll
+    for (int r = 0; r < 8; ++r) {
+      double x = racc[r].x, y = racc[r].y, u = rsw[r];
+#pragma unroll
+      for (int off = 32; off >= FT; off >>= 1) {
+        x += __shfl_xor(x, off, 64);
+        y += __shfl_xor(y, off, 64);
+        u += __shfl_xor(u, off, 64);
+      }
+      if (lane < FT) {
+        double* rp = s_red + ((size_t)(wave * 8 + r) * FT + lane) * 3;
+        rp[0] = x; rp[1] = y; rp[2] = u;
+      }
+    }
+    __syncthreads();
+    if (tid < 8 * FT) {
+      const int r = tid / FT, f = tid - r * FT;
+      double x = 0.0, y = 0.0, u = 0.0;
+#pragma unroll
+      for (int wv = 0; wv < 8; ++wv) {
+        const double* rp = s_red + ((size_t)(wv * 8 + r) * FT + f) * 3;
+        x += rp[0]; y += rp[1]; u += rp[2];
+      }
+      const size_t e = (size_t)(8 * A + r) * FT + f;
+      const f64x2 told = s_t[e];
+      s_t[e] = f64x2{told.x + x, told.y + y};
+      s_sw[e] += u;
+    }
+    __syncthreads();
+  }
+  for (int e = tid; e < nant * FT; e += GP_THREADS) {
+    const int a = e / FT, f = ft0 + (e - a * FT);
+    if (f >= nft) continue;
+    yy[(size_t)a * nft + f] = s_t[e];
+    sw_out[(size_t)a * nft + f] = s_sw[e];
+  }
+}
+
 // 8 waves: waves 0-3 run the column phase, waves 4-7 the row phase of the same sub-tile, each in a
 // loop of its own (both pass the same barriers).  A SIMD that holds one wave issues at most one
 // instruction every four cycles, scalar bookkeeping included: with both phases in the same four
@@ -778,6 +928,47 @@ int hydra_gain_weights_stream(const double* model_vis, const double* inv_noise, 
   else if (ft == 4) gain_weights_stream_kernel<4><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
   else gain_weights_stream_kernel<2><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
   HYDRA_CHECK_LAUNCH("hydra_gain_weights_stream");
+  return HYDRA_OK;
+}
+
+int hydra_gain_prepare_stream(const double* data, const double* model_vis, const double* gains,
+                              const double* inv_noise, const double* omega_r, int nbl, int nant,
+                              int nft, const int32_t* pairb, double* Wt, double* sw, double* yy,
+                              void* stream) {
+  HYDRA_CHECK_ARG(data && model_vis && gains && pairb && Wt && sw && yy && nbl > 0 && nant >= 2 && nft > 0,
+                  "hydra_gain_prepare_stream: bad arguments");
+  int nbuf;
+  size_t lds_pair;
+  int ft = gain_stream_plan(nant, &nbuf, &lds_pair);
+  HYDRA_CHECK_ARG(ft != 0, "hydra_gain_prepare_stream: %d antennas do not fit the streamed kernel", nant);
+  const int cols = 256 / ft;
+  const size_t nantp = (size_t)((nant + 7) & ~7) + cols + 8;
+  const size_t lds = nantp * ft * 40 + (size_t)8 * 8 * ft * 3 * 8;
+  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_gain_prepare_stream: %d antennas need %zu bytes of LDS", nant, lds);
+  const int nchunk = (nft + ft - 1) / ft;
+  hipStream_t st = as_stream(stream);
+  size_t count = hydra_gain_stream_weight_count(nant, nft);
+  hipError_t e = hipMemsetAsync(Wt + (count - 512), 0, 512 * sizeof(double), st);
+  if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_gain_prepare_stream: %s", hipGetErrorString(e));
+  e = hipMemsetAsync(Wt, 0, (size_t)gs_header_doubles(nant, cols) * sizeof(double), st);
+  if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_gain_prepare_stream: %s", hipGetErrorString(e));
+  gain_stream_desc_kernel<<<1, 256, 0, st>>>(nant, ft, reinterpret_cast<int4*>(Wt));
+  const long long header = gs_header_doubles(nant, cols);
+  const long long chunk_len = gs_sweep_base(gs_nsweeps(nant), nant, ft);
+#define HYDRA_GP_LAUNCH(FT_)                                                                       \
+  do {                                                                                             \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gain_prepare_stream_kernel<FT_>), lds)) \
+      return rc;                                                                                   \
+    gain_prepare_stream_kernel<FT_><<<nchunk, GP_THREADS, lds, st>>>(                              \
+        reinterpret_cast<const f64x2*>(data), reinterpret_cast<const f64x2*>(model_vis),           \
+        reinterpret_cast<const f64x2*>(gains), inv_noise, reinterpret_cast<const f64x2*>(omega_r), \
+        pairb, nant, nft, header, chunk_len, Wt, sw, reinterpret_cast<f64x2*>(yy));                \
+  } while (0)
+  if (ft == 8) HYDRA_GP_LAUNCH(8);
+  else if (ft == 4) HYDRA_GP_LAUNCH(4);
+  else HYDRA_GP_LAUNCH(2);
+#undef HYDRA_GP_LAUNCH
+  HYDRA_CHECK_LAUNCH("hydra_gain_prepare_stream");
   return HYDRA_OK;
 }
 

@@ -196,10 +196,31 @@ class GainOperator:
                       _dev.ptr(self.Wt), _dev.ptr(None), _dev.ptr(y1), st)
             self.sw = y1.real.contiguous()
 
+    @classmethod
+    def _from_stream(cls, idx, w, s, F, Wt, sw, model):
+        """Operator around stream-layout weights that ``hydra_gain_prepare_stream`` has already
+        written; ``model = (model_vis, gains)`` is kept for the by-baseline weights of the
+        batched kernels, built only if asked for."""
+        self = cls.__new__(cls)
+        self.idx, self.F, self.s = idx, F, s
+        self.nmodes = int(F.shape[0])
+        self.nft = int(np.prod(F.shape[1:]))
+        self.nbl = int(w.shape[0])
+        self._mv, self._w, self._W, self._model = None, w, None, model
+        self.n = 2 * idx.nants * self.nmodes
+        self.tiled, self.stream = True, True
+        self.Wt, self.sw = Wt, sw
+        return self
+
     @property
     def W(self):
         """The fused weight |model_vis|^2 N^-1 as (Nbl, Nft) (gain_sampler.py:278-284), for the
         pair kernels that read it by baseline; built on first use."""
+        if self._W is None and self._mv is None:
+            from . import utils
+            mv, gg = self._model
+            pairs = list(zip(self.idx.i1.tolist(), self.idx.i2.tolist()))
+            self._mv = utils.apply_gains(mv, gg, np.arange(self.idx.nants), pairs, inline=False)
         if self._W is None:
             self._W = _dev.empty((self.nbl, self.nft), torch.float64)
             _dev.call("hydra_gain_weights", _dev.ptr(self._mv), _dev.ptr(self._w),
@@ -241,6 +262,37 @@ class GainOperator:
         return _dev.like(X, self.local(Xd, add=Xd))
 
 
+def _rhs_draws(comm, myid, shape, nants, nmodes, realisation, seed, omega_y, omega_r):
+    """The fluctuation terms of the right-hand side in the reference's order
+    (gain_sampler.py:163-199): ``np.random.seed(seed)``, the root draws w_y (Nants, Nmodes) and
+    broadcasts it, then every rank draws w_r like the residual -- unless injected."""
+    sw = 1.0 if realisation else 0.0
+    np.random.seed(seed)
+    if omega_y is None:
+        if myid == 0:
+            omega_y = sw * (1.0 * np.random.randn(nants, nmodes)
+                            + 1.0j * np.random.randn(nants, nmodes)) / np.sqrt(2.0)
+        else:
+            omega_y = np.zeros((nants, nmodes), dtype=np.complex128)
+    b = np.array(omega_y, dtype=np.complex128)
+    if comm is not None:
+        comm.Bcast(b, root=0)
+    if omega_r is None:
+        omega_r = sw * (1.0 * np.random.randn(*shape)
+                        + 1.0j * np.random.randn(*shape)) / np.sqrt(2.0)
+    return b, omega_r
+
+
+def _rhs_finish(comm, yy, b, F, s, nants, nmodes, nft):
+    """[Re; Im] of  w_y + S^1/2 F^H yy, the visibility term summed over ranks."""
+    my_y = _dev.empty((1, 2 * nants * nmodes), torch.float64)
+    _dev.call("hydra_gain_basis_adj", _dev.ptr(yy), 1, nants, nmodes, nft, _dev.ptr(F),
+              _dev.ptr(s), _dev.ptr(None), _dev.ptr(my_y), _dev.stream_ptr())
+    if comm is not None:
+        comm.allreduce_(my_y)
+    return my_y[0] + _dev.f64(np.concatenate((b.flatten().real, b.flatten().imag)))
+
+
 def construct_rhs_mpi(comm, resid, inv_noise_var, pspec_sqrt, A_real, A_imag, model_vis, Fbasis,
                       realisation=True, seed=None, omega_y=None, omega_r=None):
     """Right-hand side of the gain GCR system (gain_sampler.py:145-231):
@@ -259,21 +311,8 @@ def construct_rhs_mpi(comm, resid, inv_noise_var, pspec_sqrt, A_real, A_imag, mo
     assert tuple(s.shape) == (nmodes,)
     nft = nfreqs * ntimes
     assert int(np.prod(F.shape[1:])) == nft
-    sw = 1.0 if realisation else 0.0
-
-    np.random.seed(seed)
-    if omega_y is None:
-        if myid == 0:
-            omega_y = sw * (1.0 * np.random.randn(nants, nmodes)
-                            + 1.0j * np.random.randn(nants, nmodes)) / np.sqrt(2.0)
-        else:
-            omega_y = np.zeros((nants, nmodes), dtype=np.complex128)
-    b = np.array(omega_y, dtype=np.complex128)
-    if comm is not None:
-        comm.Bcast(b, root=0)
-    if omega_r is None:
-        omega_r = sw * (1.0 * np.random.randn(nvis, nfreqs, ntimes)
-                        + 1.0j * np.random.randn(nvis, nfreqs, ntimes)) / np.sqrt(2.0)
+    b, omega_r = _rhs_draws(comm, myid, (nvis, nfreqs, ntimes), nants, nmodes, realisation, seed,
+                            omega_y, omega_r)
 
     w = _dev.f64(inv_noise_var)
     mv = _dev.c128(model_vis)
@@ -284,13 +323,62 @@ def construct_rhs_mpi(comm, resid, inv_noise_var, pspec_sqrt, A_real, A_imag, mo
     _dev.call("hydra_rhs_rows", _dev.ptr(rd), _dev.ptr(None), _dev.ptr(w), _dev.ptr(om),
               _dev.ptr(None), m, _dev.ptr(z), st)
     yy = _proj_conj_dev(z, idx, mv, nft)
-    my_y = _dev.empty((1, 2 * nants * nmodes), torch.float64)
-    _dev.call("hydra_gain_basis_adj", _dev.ptr(yy), 1, nants, nmodes, nft, _dev.ptr(F),
-              _dev.ptr(s), _dev.ptr(None), _dev.ptr(my_y), st)
-    if comm is not None:
-        comm.allreduce_(my_y)
-    bvec = my_y[0] + _dev.f64(np.concatenate((b.flatten().real, b.flatten().imag)))
+    bvec = _rhs_finish(comm, yy, b, F, s, nants, nmodes, nft)
     return _dev.like(resid, bvec)
+
+
+def prepare_sample(comm, data, model_vis, gains, inv_noise_var, pspec_sqrt, A_real, A_imag, Fbasis,
+                   realisation=True, seed=None, omega_y=None, omega_r=None):
+    """Right-hand side AND operator of one gain GCR sample from the calibrated-model inputs, i.e.
+    the driver's sequence (example.py:690-745)
+
+        ggv  = utils.apply_gains(model_vis, gains, ants, antpairs)
+        b    = construct_rhs_mpi(comm, data - ggv, inv_noise_var, pspec_sqrt, A_real, A_imag, ggv,
+                                 Fbasis, ...)
+        op   = GainOperator(inv_noise_var, pspec_sqrt, A_real, A_imag, ggv, Fbasis)
+
+    with ``gains`` (Nants, Nfreqs, Ntimes) indexed like the projectors' columns.  Returns
+    ``(b, op)``.  When the streamed pair kernel applies (no repeated pair, no auto-correlation)
+    and every baseline is listed as (lower, higher) antenna index, all of it is ONE pass over the
+    visibilities (``hydra_gain_prepare_stream``: 14 GB instead of 55 GB at HERA-331 x 64 x 64);
+    otherwise the sequence above runs as written.  Same draws, same results."""
+    from . import utils
+    myid = comm.Get_rank() if comm is not None else 0
+    idx = _index_of(A_real, A_imag)
+    dd, mv, gg = _dev.c128(data), _dev.c128(model_vis), _dev.c128(gains)
+    w = _dev.f64(inv_noise_var)
+    nvis, nfreqs, ntimes = dd.shape
+    assert tuple(mv.shape) == tuple(dd.shape) == tuple(w.shape)
+    F = _dev.c128(Fbasis)
+    nmodes, nants = int(F.shape[0]), idx.nants
+    nft = nfreqs * ntimes
+    if tuple(gg.shape[1:]) != (nfreqs, ntimes):
+        gg = gg.expand(gg.shape[0], nfreqs, ntimes).contiguous()
+    assert tuple(gg.shape) == (nants, nfreqs, ntimes) and int(np.prod(F.shape[1:])) == nft
+    count = _dev._lib.query("hydra_gain_stream_weight_count", nants, nft)
+    fused = bool(idx.pair_table is not None and count > 0 and np.all(idx.i1 < idx.i2))
+    if not fused:
+        ants = np.arange(nants)
+        pairs = list(zip(idx.i1.tolist(), idx.i2.tolist()))
+        ggv = utils.apply_gains(mv, gg, ants, pairs, inline=False)
+        b = construct_rhs_mpi(comm, dd - ggv, w, pspec_sqrt, A_real, A_imag, ggv, Fbasis,
+                              realisation=realisation, seed=seed, omega_y=omega_y, omega_r=omega_r)
+        return _dev.like(data, b), GainOperator(w, pspec_sqrt, A_real, A_imag, ggv, Fbasis)
+
+    s = _dev.f64(pspec_sqrt)
+    assert tuple(s.shape) == (nmodes,)
+    b, omega_r = _rhs_draws(comm, myid, (nvis, nfreqs, ntimes), nants, nmodes, realisation, seed,
+                            omega_y, omega_r)
+    om = _dev.c128(omega_r)
+    Wt = _dev.empty((count,), torch.float64)
+    sw = _dev.empty((nants, nft), torch.float64)
+    yy = _dev.empty((nants, nft), torch.complex128)
+    _dev.call("hydra_gain_prepare_stream", _dev.ptr(dd), _dev.ptr(mv), _dev.ptr(gg), _dev.ptr(w),
+              _dev.ptr(om), nvis, nants, nft, _dev.ptr(idx.pair_dev()), _dev.ptr(Wt), _dev.ptr(sw),
+              _dev.ptr(yy), _dev.stream_ptr())
+    bvec = _rhs_finish(comm, yy, b, F, s, nants, nmodes, nft)
+    op = GainOperator._from_stream(idx, w, s, F, Wt, sw, model=(mv, gg))
+    return _dev.like(data, bvec), op
 
 
 def apply_operator_mpi(comm, x, inv_noise_var, pspec_sqrt, A_real, A_imag, model_vis, Fbasis):

@@ -488,6 +488,23 @@ int hydra_gain_weights_stream(const double* model_vis, const double* inv_noise, 
 int hydra_gain_pairs_stream(const double* g, int nant, int nft, const double* Wt, const double* sw,
                             double* y, void* stream);
 
+/* Everything a gain GCR sample needs from the visibilities, in ONE pass over them -- the
+ * driver's sequence example.py:690-745: ggv = apply_gains(model) (utils.py:63-110), resid = data -
+ * ggv, the visibility half of construct_rhs_mpi (gain_sampler.py:201-213: z = resid N^-1 +
+ * omega_r N^-1/2, A^H z with model_vis = ggv) and the operator weights |ggv|^2 N^-1
+ * (gain_sampler.py:278-284).  For pair lists as for hydra_gain_pairs_stream whose baselines are
+ * all listed as (lower antenna index, higher antenna index).
+ *   data, model_vis, omega_r (Nbl,Nft) c128 (omega_r NULL: 0), inv_noise (Nbl,Nft) f64 (NULL: 1),
+ *   gains (Nant,Nft) c128, pairb as for hydra_gain_pairs_tiled;
+ *   Wt: stream layout, hydra_gain_stream_weight_count doubles (same content as
+ *       hydra_gain_weights_stream on ggv);
+ *   sw (Nant,Nft) f64 = sum_{b in adj(a)} W[b];
+ *   yy (Nant,Nft) c128 = apply_proj_conj(z) -- feed to hydra_gain_basis_adj for the RHS.          */
+int hydra_gain_prepare_stream(const double* data, const double* model_vis, const double* gains,
+                              const double* inv_noise, const double* omega_r, int nbl, int nant,
+                              int nft, const int32_t* pairb, double* Wt, double* sw, double* yy,
+                              void* stream);
+
 /* apply_proj: out[b,f,t] = (x_i + conj(x_j)) model_vis[b,f,t]    gain_sampler.py:81-106 */
 int hydra_gain_proj(const double* x, const int32_t* bl_i, const int32_t* bl_j, int nbl,
                     const double* model_vis, int nft, double* out, void* stream);

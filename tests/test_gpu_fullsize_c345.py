@@ -198,6 +198,65 @@ def test_c4_operator_is_symmetric_and_batch_equals_single(c4):
     assert float((Z - (X[0] + Y[0])).abs().max()) <= 1e-13 * float(Z.abs().max())
 
 
+def test_c4_one_pass_preparation_matches_separate_passes_and_oracle_on_slices(c4):
+    """gain_sampler.prepare_sample at HERA-331 x 64 x 64: right-hand side and stream weights equal
+    to the separate passes (apply_gains, residual, construct_rhs_mpi, GainOperator), and the
+    antenna-space term A^H (N^-1 r + N^-1/2 omega) equal to the oracle's on (f,t) slices
+    (gain_sampler.py:145-231; the projection is point-wise in (f,t))."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import _dev, gain_sampler as gs
+    from oracle import gcr_gain
+    op0, nant, nf, nt, dev, gen = c4["op"], c4["nant"], c4["nf"], c4["nt"], c4["dev"], c4["gen"]
+    ants, antpairs = c4["ants"], c4["antpairs"]
+    nbl, nft = op0.nbl, nf * nt
+    shape = (nbl, nf, nt)
+    model, w, ps, Fb = c4["mv"], c4["w"], c4["ps"], c4["Fb"]
+    gains = 1.0 + 0.1 * torch.randn((nant, nf, nt), dtype=torch.complex128, device=dev, generator=gen)
+    data = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    om_r = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    rng = np.random.RandomState(5)
+    om_y = rng.randn(nant, op0.nmodes) + 1j * rng.randn(nant, op0.nmodes)
+    A_real, A_imag = gs.proj_operator(ants, antpairs)
+    b1, op1 = gs.prepare_sample(None, data, model, gains, w, ps, A_real, A_imag, Fb,
+                                omega_y=om_y, omega_r=om_r)
+    assert op1._mv is None                                   # the one-pass form ran
+    ggv = hy.utils.apply_gains(model, gains, ants, antpairs, inline=False)
+    resid = data - ggv
+    b0 = gs.construct_rhs_mpi(None, resid, w, ps, A_real, A_imag, ggv, Fb, omega_y=om_y,
+                              omega_r=om_r)
+    assert float((b1 - b0).abs().max()) <= 1e-12 * float(b0.abs().max())
+    op2 = gs.GainOperator(w, ps, A_real, A_imag, ggv, Fb)
+    assert float((op1.Wt - op2.Wt).abs().max()) <= 1e-13 * float(op2.Wt.abs().max())
+    assert float((op1.sw - op2.sw).abs().max()) <= 1e-12 * float(op2.sw.abs().max())
+    x = torch.randn(op2.n, dtype=torch.float64, device=dev, generator=gen)
+    y1, y2 = op1.apply(x), op2.apply(x)
+    assert float((y1 - y2).abs().max()) <= 1e-12 * float(y2.abs().max())
+    # oracle on slices: yy = A^H z straight from the kernel
+    count = _dev._lib.query("hydra_gain_stream_weight_count", nant, nft)
+    Wt, sw = _dev.empty((count,), torch.float64), _dev.empty((nant, nft), torch.float64)
+    yy = _dev.empty((nant, nft), torch.complex128)
+    _dev.call("hydra_gain_prepare_stream", _dev.ptr(data), _dev.ptr(model), _dev.ptr(gains),
+              _dev.ptr(w), _dev.ptr(om_r), nbl, nant, nft, _dev.ptr(op1.idx.pair_dev()),
+              _dev.ptr(Wt), _dev.ptr(sw), _dev.ptr(yy), _dev.stream_ptr())
+    fsel, tsel = np.array([0, 31, 63]), np.array([0, 17, 63])
+    ftd = torch.as_tensor((fsel[:, None] * nt + tsel[None, :]).reshape(-1), device=dev)
+    i1, i2 = gcr_gain.bl_indices(ants, antpairs)
+    sl = lambda a, n: a.reshape(n, nft)[:, ftd].cpu().numpy().reshape(n, 3, 3)
+    g_s, m_s, d_s, w_s, o_s = sl(gains, nant), sl(model, nbl), sl(data, nbl), sl(w, nbl), sl(om_r, nbl)
+    ggv_s = m_s * g_s[i1] * np.conj(g_s[i2])
+    z_s = (d_s - ggv_s) * w_s + o_s * np.sqrt(w_s)
+    yy_ref = gcr_gain.apply_proj_conj(z_s, i1, i2, ggv_s, (nant, 3, 3))
+    yy_got = sl(yy, nant)
+    assert relerr(yy_got, yy_ref) < 1e-11
+    assert elem_err(yy_got, yy_ref) <= 1.0
+    sw_ref = np.zeros((nant, 3, 3))
+    Wb = np.abs(ggv_s) ** 2 * w_s
+    np.add.at(sw_ref, i1, Wb)
+    np.add.at(sw_ref, i2, Wb)
+    assert relerr(sl(sw, nant), sw_ref) < 1e-12
+
+
 # ------------------------------------------------------------------------------------- c5
 
 def _c5_layout():

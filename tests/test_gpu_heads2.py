@@ -667,3 +667,65 @@ def test_streamed_gain_pairs_layouts(hy, nant, nft):
     # every weight sits in exactly one slot of the stream layout
     assert abs(float(Wt.sum()) - float(W.sum())) <= 1e-12 * float(W.sum())
     assert _dev._lib.query("hydra_gain_stream_weight_count", 1800, nft) == 0
+
+
+@pytest.mark.parametrize("nant,nf,nt,holes,flip", [(12, 3, 5, False, False), (40, 4, 8, True, False),
+                                                   (9, 1, 3, False, False), (380, 3, 7, True, False),
+                                                   (14, 2, 5, False, True)])
+def test_gain_prepare_sample_matches_the_unfused_sequence(hy, nant, nf, nt, holes, flip):
+    """gain_sampler.prepare_sample (one pass over the visibilities: hydra_gain_prepare_stream)
+    against the driver's sequence apply_gains -> residual -> construct_rhs_mpi -> GainOperator
+    (example.py:690-745, gain_sampler.py:145-231, 278-284): same right-hand side, same stream
+    weights, same diagonal term, same operator.  `flip` lists some baselines as (higher, lower):
+    prepare_sample must then run the sequence itself."""
+    import torch
+    from hydra_amd import gain_sampler as gs
+    rng = np.random.RandomState(100 + nant)
+    pairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    if holes:
+        pairs = [p for p in pairs if rng.rand() > 0.15]
+    if flip:
+        pairs = [(j, i) if k % 3 == 0 else (i, j) for k, (i, j) in enumerate(pairs)]
+    nbl = len(pairs)
+    ants = np.arange(nant)
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(nant)
+    shape = (nbl, nf, nt)
+    model = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    data = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    w = 0.5 + torch.rand(shape, dtype=torch.float64, device=dev, generator=gen)
+    gains = 1.0 + 0.3 * torch.randn((nant, nf, nt), dtype=torch.complex128, device=dev, generator=gen)
+    om_r = torch.randn(shape, dtype=torch.complex128, device=dev, generator=gen)
+    freqs, times = np.linspace(100., 120., nf), np.linspace(0.1, 0.4, nt)
+    Fb, _, _ = hy.utils.partial_fourier_basis_2d_from_nmax(freqs, times, 1, 1, 20., 0.3)
+    nmodes = Fb.shape[0]
+    Fb = torch.as_tensor(np.ascontiguousarray(Fb), device=dev)
+    ps = torch.as_tensor(0.1 + rng.rand(nmodes), device=dev)
+    om_y = rng.randn(nant, nmodes) + 1j * rng.randn(nant, nmodes)
+    A_real, A_imag = gs.proj_operator(ants, pairs)
+
+    ggv = hy.utils.apply_gains(model, gains, ants, pairs, inline=False)
+    b0 = gs.construct_rhs_mpi(None, data - ggv, w, ps, A_real, A_imag, ggv, Fb,
+                              omega_y=om_y, omega_r=om_r)
+    op0 = gs.GainOperator(w, ps, A_real, A_imag, ggv, Fb)
+    b1, op1 = gs.prepare_sample(None, data, model, gains, w, ps, A_real, A_imag, Fb,
+                                omega_y=om_y, omega_r=om_r)
+    assert (op1._mv is None) == (not flip)            # the one-pass form ran unless told otherwise
+    assert float((b1 - b0).abs().max()) <= 1e-12 * float(b0.abs().max())
+    x = torch.as_tensor(rng.randn(op0.n), device=dev)
+    y0, y1 = op0.apply(x), op1.apply(x)
+    assert float((y1 - y0).abs().max()) <= 1e-12 * float(y0.abs().max())
+    if op0.stream:
+        assert float((op1.Wt - op0.Wt).abs().max()) <= 1e-13 * float(op0.Wt.abs().max())
+        assert float((op1.sw - op0.sw).abs().max()) <= 1e-12 * float(op0.sw.abs().max())
+    X = torch.as_tensor(rng.randn(3, op0.n), device=dev)     # batched form: by-baseline weights
+    Y0, Y1 = op0.apply(X), op1.apply(X)
+    assert float((Y1 - Y0).abs().max()) <= 1e-12 * float(Y0.abs().max())
+    # numpy in, numpy out, and the reference's own draws when nothing is injected
+    bn, _ = gs.prepare_sample(None, data.cpu().numpy(), model.cpu().numpy(), gains.cpu().numpy(),
+                              w.cpu().numpy(), ps.cpu().numpy(), A_real, A_imag, Fb.cpu().numpy(),
+                              seed=11)
+    bs = gs.construct_rhs_mpi(None, (data - ggv).cpu().numpy(), w.cpu().numpy(), ps.cpu().numpy(),
+                              A_real, A_imag, ggv.cpu().numpy(), Fb.cpu().numpy(), seed=11)
+    assert isinstance(bn, np.ndarray)
+    assert np.abs(bn - bs).max() <= 1e-12 * np.abs(bs).max()
