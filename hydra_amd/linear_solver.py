@@ -79,7 +79,10 @@ def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
         out = linear_op(v if as_torch else v.cpu().numpy())
         return _dev.f64(out)
 
-    _dev.call("hydra_cg_init", n, _dev.ptr(b), _dev.ptr(op(x)), _dev.ptr(r), _dev.ptr(p),
+    # r = b - A x0 (linear_solver.py:433-446); without a starting guess x0 = 0 and A x0 = 0 for any
+    # linear operator, so that application (one of 25 at config 4) is not made
+    ax0 = op(x) if x0 is not None else torch.zeros_like(b)
+    _dev.call("hydra_cg_init", n, _dev.ptr(b), _dev.ptr(ax0), _dev.ptr(r), _dev.ptr(p),
               _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
     it = 0
     every = CHECK_EVERY if as_torch else 1     # a numpy operator synchronises every call anyway
