@@ -351,7 +351,7 @@ __device__ __forceinline__ f64x4 mfma64(double a, double b, f64x4 c) {
 __global__ void __launch_bounds__(256, 2)
 chol_syrk_mfma_kernel(double* __restrict__ C, long long ldc, const double* __restrict__ PA,
                       long long lda, const double* __restrict__ PB, long long ldb, int mrows,
-                      int ncols, int diag, int ntr, int nsup, int ntc) {
+                      int ncols, int diag, int ntr, int nsup, int ntc, int nkc) {
   __shared__ __align__(16) unsigned char smem[2 * STG_BYTES];
   int ti, tj;
   if (nsup > 0) {
@@ -427,11 +427,11 @@ chol_syrk_mfma_kernel(double* __restrict__ C, long long ldc, const double* __res
   const unsigned char* rdB = smem + CT * KC * 8 + (wc * 64 + lr) * (KC * 8);
   const int p0 = ((0 + g) ^ swz) * 16, p1 = ((4 + g) ^ swz) * 16;
 
-  for (int kc = 0; kc < NKC; ++kc) {
+  for (int kc = 0; kc < nkc; ++kc) {
     const int buf = kc & 1;
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");   // this wave's pieces of chunk kc have landed
     __syncthreads();                                   // ... everyone's; stage buf^1 is free again
-    const bool more = kc + 1 < NKC;
+    const bool more = kc + 1 < nkc;
     const unsigned char* sa = rdA + buf * STG_BYTES;
     const unsigned char* sb = rdB + buf * STG_BYTES;
     // Reads in the order of use (first half of the chunk's k-values, then the second: the second
@@ -570,29 +570,57 @@ static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_
   return HYDRA_OK;
 }
 
+// Columns are finished 256 at a time (32-wide steps capped at the sub-panel's last column), but the
+// rest of the matrix is updated once per SUPER-panel of SPW columns with K = SPW: per 128 x 128 tile
+// the 128 KB of C come in and go out once per SPW / 4 matrix instructions per wave instead of once
+// per 64.  Timing builds of the update kernel with the C loads or stores removed showed what they
+// cost at K = 256: 0.76 -> 0.85 / 0.84 of the matrix peak, 0.90 without both -- each workgroup alone
+// nearly fills the matrix pipe, so a second one on the CU cannot hide the other's memory phases.
+// Inside a super-panel the columns still to be factored take a rank-256 update from every finished
+// sub-panel (the same kernel, a rectangle of at most SPW - 256 columns: under 2 % of the flops).
+#ifndef HYDRA_CHOL_SPW
+#define HYDRA_CHOL_SPW 2048
+#endif
+static constexpr int SPW = HYDRA_CHOL_SPW;
+static_assert(SPW % PB == 0, "super-panel = whole 256-wide panels");
+
 static int chol_factor_blocked(double* A, int n, int32_t* info_dev, hipStream_t s) {
   dim3 tb(NB, NB);
-  for (int k = 0; k < n; k += PB) {
-    const int pb = std::min(PB, n - k), col_end = k + pb;
-    potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, k, info_dev);
-    for (int kk = k; kk < col_end; kk += NB) {
-      const int nb = std::min(NB, n - kk), rest = n - kk - nb;
-      if (rest <= 0) break;
-      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, kk);
-      const int ncols = col_end - (kk + NB);
-      if (ncols > 0)   // update the panel's remaining columns (+ potrf of the next 32-block)
-        syrk_update_kernel<<<dim3((ncols + SY_T - 1) / SY_T, (rest + SY_T - 1) / SY_T), 256, 0, s>>>(
-            A, n, kk, col_end, info_dev);
+  for (int k0 = 0; k0 < n; k0 += SPW) {
+    const int sp_end = std::min(k0 + SPW, n);
+    for (int k = k0; k < sp_end; k += PB) {
+      const int pb = std::min(PB, n - k), col_end = k + pb;
+      potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, k, info_dev);
+      for (int kk = k; kk < col_end; kk += NB) {
+        const int nb = std::min(NB, n - kk), rest = n - kk - nb;
+        if (rest <= 0) break;
+        trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, kk);
+        const int ncols = col_end - (kk + NB);
+        if (ncols > 0)   // update the panel's remaining columns (+ potrf of the next 32-block)
+          syrk_update_kernel<<<dim3((ncols + SY_T - 1) / SY_T, (rest + SY_T - 1) / SY_T), 256, 0, s>>>(
+              A, n, kk, col_end, info_dev);
+      }
+      const int wrest = sp_end - col_end;        // columns of the super-panel still to be factored
+      if (wrest > 0) {                            // then this sub-panel is full (pb == PB)
+        const int mrows = n - col_end;
+        const int ntr = (mrows + CT - 1) / CT, ntc = (wrest + CT - 1) / CT;
+        const long long grid = (long long)ntr * ntc;
+        if (grid > 2147483647LL) return fail(HYDRA_ERR_ARG, "hydra_chol_solve: n=%d is too large", n);
+        const double* P = A + (size_t)col_end * n + k;
+        chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, s>>>(A + (size_t)col_end * n + col_end, n, P, n,
+                                                             P, n, mrows, wrest, 0, ntr, 0, ntc, NKC);
+      }
     }
-    const int rest = n - col_end;
-    if (rest > 0) {   // then the panel is full (pb == PB)
+    const int rest = n - sp_end;
+    if (rest > 0) {   // then the super-panel is full
       const int ntr = (rest + CT - 1) / CT, nsr = (ntr + SUP - 1) / SUP;
       const long long nsup = (long long)nsr * (nsr + 1) / 2;
       const long long grid = (nsup + 7) / 8 * 8 * SUP * SUP;
       if (grid > 2147483647LL) return fail(HYDRA_ERR_ARG, "hydra_chol_solve: n=%d is too large", n);
-      const double* P = A + (size_t)col_end * n + k;            // the finished panel, in place
-      chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, s>>>(A + (size_t)col_end * n + col_end, n, P, n,
-                                                           P, n, rest, rest, 0, ntr, (int)nsup, ntr);
+      const double* P = A + (size_t)sp_end * n + k0;              // the finished super-panel, in place
+      chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, s>>>(A + (size_t)sp_end * n + sp_end, n, P, n,
+                                                           P, n, rest, rest, 0, ntr, (int)nsup, ntr,
+                                                           SPW / KC);
     }
   }
   HYDRA_CHECK_LAUNCH("hydra_chol_solve(blocked factor)");
@@ -662,7 +690,7 @@ int hydra_chol_update_rect(double* C, long long ldc, const double* PA, long long
   const long long grid = (long long)ntr * ntc;
   HYDRA_CHECK_ARG(grid <= 2147483647LL, "hydra_chol_update_rect: too many tiles");
   chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(C, ldc, PA, lda, PB, ldb, mrows,
-                                                                       ncols, diag, ntr, 0, ntc);
+                                                                       ncols, diag, ntr, 0, ntc, NKC);
   HYDRA_CHECK_LAUNCH("hydra_chol_update_rect");
   return HYDRA_OK;
 }
