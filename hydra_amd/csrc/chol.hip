@@ -329,7 +329,6 @@ constexpr int KC = 16;            // k-values per LDS stage
 constexpr int NKC = PB / KC;
 constexpr int STG_BYTES = 2 * CT * KC * 8;   // one stage: A strip + B strip = 32 KiB
 constexpr int SUP = 8;            // tiles per edge of the patch one XCD works on at a time
-constexpr int PB_WIDTH_ABI = PB;  // hydra_chol_update_rect: K of the update
 
 __device__ __forceinline__ void tri_of(int p, int* i, int* j) {   // p = i (i+1)/2 + j, j <= i
   int a = (int)((sqrt(8.0 * p + 1.0) - 1.0) * 0.5);
@@ -675,11 +674,12 @@ int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, voi
 }
 
 int hydra_chol_update_rect(double* C, long long ldc, const double* PA, long long lda,
-                           const double* PB, long long ldb, int mrows, int ncols, int diag,
+                           const double* PB, long long ldb, int mrows, int ncols, int diag, int kdim,
                            void* stream) {
-  HYDRA_CHECK_ARG(C && PA && PB && mrows > 0 && ncols > 0 && ldc >= ncols && lda >= PB_WIDTH_ABI &&
-                      ldb >= PB_WIDTH_ABI,
-                  "hydra_chol_update_rect: bad arguments (mrows=%d ncols=%d)", mrows, ncols);
+  HYDRA_CHECK_ARG(C && PA && PB && mrows > 0 && ncols > 0 && kdim >= KC && kdim % KC == 0 &&
+                      ldc >= ncols && lda >= kdim && ldb >= kdim,
+                  "hydra_chol_update_rect: bad arguments (mrows=%d ncols=%d kdim=%d)", mrows, ncols,
+                  kdim);
   HYDRA_CHECK_ARG(reinterpret_cast<uintptr_t>(PA) % 16 == 0 && reinterpret_cast<uintptr_t>(PB) % 16 == 0 &&
                       lda % 2 == 0 && ldb % 2 == 0,
                   "hydra_chol_update_rect: operand rows must be 16-byte aligned");
@@ -690,7 +690,8 @@ int hydra_chol_update_rect(double* C, long long ldc, const double* PA, long long
   const long long grid = (long long)ntr * ntc;
   HYDRA_CHECK_ARG(grid <= 2147483647LL, "hydra_chol_update_rect: too many tiles");
   chol_syrk_mfma_kernel<<<(unsigned)grid, 256, 0, as_stream(stream)>>>(C, ldc, PA, lda, PB, ldb, mrows,
-                                                                       ncols, diag, ntr, 0, ntc, NKC);
+                                                                       ncols, diag, ntr, 0, ntc,
+                                                                       kdim / KC);
   HYDRA_CHECK_LAUNCH("hydra_chol_update_rect");
   return HYDRA_OK;
 }

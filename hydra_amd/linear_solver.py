@@ -233,6 +233,10 @@ class RowShardedOperator:
         return _dev.like(v, self.comm.allgather_rows(self.y[:nloc], self.n))
 
 
+#: columns per trailing update of the row-sharded factorisation (csrc/chol.hip: HYDRA_CHOL_SPW)
+SUPER_PANEL = 2048
+
+
 def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
     """The dense solve of the driver (``scipy.linalg.solve(A, b, assume_a='her')``,
     example.py:940-947) for an operator sharded by rows over the ranks of ``comm`` -- the layout
@@ -240,14 +244,16 @@ def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
     ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n), ``bvec`` (n,) is the same on every rank.
     Returns x (n,) on every rank.
 
-    Right-looking Cholesky with 256-wide panels, every rank working on its own rows: per panel the
-    256 x 256 diagonal block is summed to all ranks (each owns some of its rows) and factored by
-    everyone, every rank solves its rows of the panel against it, the panel is all-gathered
-    (n x 256 doubles), and every rank updates its rows of the trailing matrix on the FP64 matrix
-    cores (``hydra_chol_update_rect``, the kernel of the one-GPU factorisation).  The two
-    triangular solves then walk the row blocks in order, one broadcast per block.  Work per rank
-    is its rows' share of the triangle (the last block has 2 - 1/size times the mean).
-    n must be even.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
+    Right-looking Cholesky, every rank working on its own rows.  Columns are finished 256 at a
+    time: the 256 x 256 diagonal block is summed to all ranks (each owns some of its rows) and
+    factored by everyone, every rank solves its rows of the panel against it, and the panel is
+    all-gathered (n x 256 doubles).  As in the one-GPU routine (csrc/chol.hip, "super-panels") the
+    matrix right of a SUPER-panel of 2048 columns is updated once, with K = 2048, on the FP64 matrix
+    cores (``hydra_chol_update_rect``: one round trip of C per 2048 columns instead of per 256);
+    inside the super-panel the columns still to be factored take a rank-256 update from each
+    finished panel.  The two triangular solves then walk the row blocks in order, one broadcast per
+    block.  Work per rank is its rows' share of the triangle (the last block has 2 - 1/size times
+    the mean).  n must be even.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
     A = _dev.f64(A_rows)
     if not (overwrite_a and A is A_rows):
         A = A.clone()
@@ -260,49 +266,66 @@ def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
     assert n % 2 == 0, "solve_dense_rows: n must be even (rows are moved in 16-byte pieces)"
     per = -(-n // size)
     dev, st = A.device, _dev.stream_ptr()
-    PBW = 256
+    PBW, SPW = 256, SUPER_PANEL
     info = _dev.zeros((1,), torch.int32)
     bad = _dev.zeros((1,), torch.int32)
     dummy = torch.zeros(PBW, dtype=torch.float64, device=dev)
-    # (rows above the panel's end are never read from these two: no clearing per panel)
+    # (rows above the panel's end are never read from these: no clearing per panel)
     mine = torch.zeros((per, PBW), dtype=torch.float64, device=dev)
     panel = torch.empty((size * per, PBW), dtype=torch.float64, device=dev)
-    for k in range(0, n, PBW):
-        pb = min(PBW, n - k)
-        kend = k + pb
-        # diagonal block: every rank contributes the rows it owns
-        D = torch.zeros((pb, pb), dtype=torch.float64, device=dev)
-        d0, d1 = max(r0, k), min(r1, kend)
-        if d1 > d0:
-            D[d0 - k:d1 - k] = A[d0 - r0:d1 - r0, k:kend]
-        comm.allreduce_(D)
-        D = torch.tril(D)
-        D = D + torch.tril(D, -1).T
-        dummy.zero_()
-        _dev.call("hydra_chol_solve", _dev.ptr(D), _dev.ptr(dummy), pb, _dev.ptr(info), st)
-        bad |= info
-        L = torch.tril(D)
-        if d1 > d0:
-            A[d0 - r0:d1 - r0, k:kend] = L[d0 - k:d1 - k]
-        # this rank's rows of the panel below the block: X L^T = P
-        i0 = max(r0, kend)
-        rest = n - kend
-        if r1 > i0:
-            X = mine[i0 - r0:nloc] if rest > 0 else torch.empty((r1 - i0, pb), dtype=torch.float64,
-                                                                device=dev)
-            torch.linalg.solve_triangular(L.T, A[i0 - r0:, k:kend].contiguous(), upper=True,
-                                          left=False, out=X)
-            A[i0 - r0:, k:kend] = X
-        if rest <= 0:
-            break
-        # the whole panel, in global row order, on every rank
-        comm.allgather_into_(panel, mine)
-        if r1 > i0:
-            mrows, ncols = r1 - i0, r1 - kend
-            c_off = ((i0 - r0) * n + kend) * 8
-            a_off = ((i0 - r0) * n + k) * 8
-            _dev.call("hydra_chol_update_rect", A.data_ptr() + c_off, n, A.data_ptr() + a_off, n,
-                      panel.data_ptr() + kend * PBW * 8, PBW, mrows, ncols, i0 - kend, st)
+    spanel = torch.empty((size * per, SPW), dtype=torch.float64, device=dev) if n > SPW else None
+
+    def update(i0, c0, c1, k_lo, k_hi, pb_rows, ldb):
+        """My rows i >= i0 of columns [c0, c1) take the rank-(k_hi - k_lo) update from columns
+        [k_lo, k_hi) of my rows (PA) and of the gathered rows c0.. (PB)."""
+        if r1 <= i0 or c1 <= c0:
+            return
+        mrows, ncols = r1 - i0, min(c1, r1) - c0
+        if ncols <= 0:
+            return
+        _dev.call("hydra_chol_update_rect", A.data_ptr() + ((i0 - r0) * n + c0) * 8, n,
+                  A.data_ptr() + ((i0 - r0) * n + k_lo) * 8, n, pb_rows, ldb, mrows, ncols,
+                  i0 - c0, k_hi - k_lo, st)
+
+    for k0 in range(0, n, SPW):
+        sp_end = min(k0 + SPW, n)
+        for k in range(k0, sp_end, PBW):
+            pb = min(PBW, n - k)
+            kend = k + pb
+            # diagonal block: every rank contributes the rows it owns
+            D = torch.zeros((pb, pb), dtype=torch.float64, device=dev)
+            d0, d1 = max(r0, k), min(r1, kend)
+            if d1 > d0:
+                D[d0 - k:d1 - k] = A[d0 - r0:d1 - r0, k:kend]
+            comm.allreduce_(D)
+            D = torch.tril(D)
+            D = D + torch.tril(D, -1).T
+            dummy.zero_()
+            _dev.call("hydra_chol_solve", _dev.ptr(D), _dev.ptr(dummy), pb, _dev.ptr(info), st)
+            bad |= info
+            L = torch.tril(D)
+            if d1 > d0:
+                A[d0 - r0:d1 - r0, k:kend] = L[d0 - k:d1 - k]
+            # this rank's rows of the panel below the block: X L^T = P
+            i0 = max(r0, kend)
+            rest = n - kend
+            if r1 > i0:
+                X = mine[i0 - r0:nloc] if rest > 0 else torch.empty((r1 - i0, pb), dtype=torch.float64,
+                                                                    device=dev)
+                torch.linalg.solve_triangular(L.T, A[i0 - r0:, k:kend].contiguous(), upper=True,
+                                              left=False, out=X)
+                A[i0 - r0:, k:kend] = X
+            if rest <= 0:
+                break
+            # the whole panel, in global row order, on every rank
+            comm.allgather_into_(panel, mine)
+            if spanel is not None and n > sp_end:
+                spanel[kend:, k - k0:kend - k0] = panel[kend:]
+            # the columns of this super-panel that are still to be factored
+            update(i0, kend, sp_end, k, kend, panel.data_ptr() + kend * PBW * 8, PBW)
+        if n > sp_end:
+            # everything right of the super-panel, once, with K = its width
+            update(max(r0, sp_end), sp_end, n, k0, sp_end, spanel.data_ptr() + sp_end * SPW * 8, SPW)
     comm.allreduce_(bad, op="max")
     if int(bad.item()) != 0:
         raise np.linalg.LinAlgError("matrix is not positive definite")

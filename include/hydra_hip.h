@@ -384,14 +384,15 @@ int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, voi
 
 /* The trailing update of that factorisation as a building block for matrices sharded by rows over
  * GPUs (hydra_amd.linear_solver.solve_dense_rows; the same dense solve, example.py:940-947):
- *   C[i][j] -= sum_{k < 256} PA[i][k] PB[j][k]   for i < mrows, j < ncols, j <= i + diag
+ *   C[i][j] -= sum_{k < kdim} PA[i][k] PB[j][k]   for i < mrows, j < ncols, j <= i + diag
  * on the FP64 matrix cores.  C (mrows, >= ncols) with row stride ldc: the rank's rows of the
- * matrix right of the panel; PA (mrows, 256), row stride lda: the same rows of the finished panel;
- * PB (ncols, 256), row stride ldb: the panel rows that belong to C's columns (gathered from all
- * ranks); diag = (global row of C's first row) - (global column of C's first column).  PA, PB
- * 16-byte aligned with even strides.                                                        */
+ * matrix right of the panel; PA (mrows, kdim), row stride lda: the same rows of the finished
+ * panel(s); PB (ncols, kdim), row stride ldb: the panel rows that belong to C's columns (gathered
+ * from all ranks); diag = (global row of C's first row) - (global column of C's first column);
+ * kdim a multiple of 16 (256 per panel, 2048 per super-panel).  PA, PB 16-byte aligned with even
+ * strides.                                                                                     */
 int hydra_chol_update_rect(double* C, long long ldc, const double* PA, long long lda,
-                           const double* PB, long long ldb, int mrows, int ncols, int diag,
+                           const double* PB, long long ldb, int mrows, int ncols, int diag, int kdim,
                            void* stream);
 
 /* ---- spherical-harmonic response (simulate_vis_per_alm) -------------------------- */

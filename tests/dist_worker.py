@@ -482,7 +482,11 @@ def case_cholrows(comm):
     from hydra_amd import linear_solver
     rank, size = comm.Get_rank(), comm.Get_size()
     dev = torch.device("cuda")
-    for n in (2, 254, 256, 258, 700, 1026):
+    # (n, super-panel width): the default 2048 on both sides of its edge, and narrow super-panels
+    # so that several trailing updates with K = 512 follow one another at a small size
+    for n, spw in ((2, 2048), (254, 2048), (256, 2048), (258, 2048), (700, 2048), (1026, 2048),
+                   (1026, 512), (1300, 512), (2306, 2048)):
+        linear_solver.SUPER_PANEL = spw
         rng = np.random.RandomState(n)
         B = rng.randn(n, n + 5)
         A = B @ B.T / n + np.eye(n)
@@ -494,6 +498,7 @@ def case_cholrows(comm):
         got = x.cpu().numpy()
         assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want)), (n, np.max(np.abs(got - want)))
         assert torch.equal(rows, torch.as_tensor(A[r0:r1], device=dev))      # input untouched
+    linear_solver.SUPER_PANEL = 2048
     # not positive definite: every rank raises
     A = -np.eye(300)
     r0, r1 = comm.row_range(300)

@@ -14,7 +14,7 @@ for ldc, ldp in [(m, 256), (m, m), (65536, 256), (100000, 256), (100000, 100000)
     C = torch.zeros((m, ldc), dtype=torch.float64, device=dev)
     P = torch.randn((m, ldp), dtype=torch.float64, device=dev)
     st = _dev.stream_ptr()
-    args = (_dev.ptr(C), ldc, _dev.ptr(P), ldp, _dev.ptr(P), ldp, m, m, m, st)   # diag = m: every tile
+    args = (_dev.ptr(C), ldc, _dev.ptr(P), ldp, _dev.ptr(P), ldp, m, m, m, 256, st)   # diag = m: every tile
     _dev.call("hydra_chol_update_rect", *args)
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
