@@ -794,6 +794,15 @@ adjbig_frag_kernel(const f64x2* __restrict__ zt, const int32_t* __restrict__ tab
 // zero at the next dependent use in the wave that issued it -- one full memory latency per group of
 // MFMAs.  In a wave of its own it delays nobody.
 constexpr int AB_THREADS = 320;
+#ifdef HYDRA_GRAM_STAMPS
+// diagnostic build only: per-wave timeline of workgroup 0's third (f,t): [wave][arrival at the
+// barrier, past it, first row block done, all row blocks done]
+__device__ unsigned long long g_adj_trace[8][8];
+#define ADJ_STAMP(var)                                                                   \
+  __builtin_amdgcn_sched_barrier(0);                                                     \
+  asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
+  __builtin_amdgcn_sched_barrier(0);
+#endif
 
 __global__ void __launch_bounds__(AB_THREADS)
 adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int nr,
@@ -812,15 +821,35 @@ adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int
   // LDS-DMA of one (f,t) tile: a piece = 2 antenna rows x 32 sources = 1 KiB.  Rows beyond Nant
   // repeat row Nant-1 (they only meet zero entries of Zc), sources beyond Ns repeat source Ns-1
   // (their sums are not stored).
+  // The stager's loop is scalar instructions plus the DMA itself: while a SIMD executes FP64
+  // matrix instructions back to back, another wave's VECTOR instructions get in about once per
+  // matrix instruction (measured: 14 instructions per piece, 9 of them vector address arithmetic,
+  // took 320 cycles per piece -- the 64 pieces of a tile the whole compute phase, and the barrier
+  // waited for them; raising the wave's priority changed nothing).  So the per-lane part of the
+  // address is one constant offset, the rest is a scalar base.  The DMA is issued by inline asm
+  // (see gram_uniform_kernel in gram.hip).
   const unsigned lane_off = (unsigned)min(s0 + (lane & 31), ns - 1) * 16u;
+  const unsigned voff2 = lane_off + (unsigned)(lane >> 5) * (unsigned)ns * 16u;   // two rows
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
   auto stage = [&](int ft, int buf) {
     const char* vft = reinterpret_cast<const char*>(V + (size_t)ft * nant * ns);
-    for (int q = 0; q < nap / 2; ++q) {
-      const int row = min(2 * q + (lane >> 5), nant - 1);
-      const char* src = vft + (size_t)row * ns * 16 + lane_off;
-      f64x2* dst = s_v + ((size_t)buf * nap + 2 * q) * AB_SRC;
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)dst, 16, 0, 0);
+    const size_t row_bytes = (size_t)ns * 16;
+    unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)((size_t)buf * nap * AB_SRC * 16));
+    const int nfull = nant / 2;                      // pieces whose two rows both exist
+    const char* src = vft;
+    for (int q = 0; q < nfull; ++q) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(dst), "v"(voff2), "s"(src) : "memory");
+      src += 2 * row_bytes;
+      dst += 2 * AB_SRC * 16;
+    }
+    // rows beyond Nant repeat row Nant-1 (both halves of the piece read the same row)
+    const char* last = vft + (size_t)(nant - 1) * row_bytes;
+    for (int q = nfull; q < nap / 2; ++q) {
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                   :: "s"(dst), "v"(lane_off), "s"(last) : "memory");
+      dst += 2 * AB_SRC * 16;
     }
   };
 
@@ -835,10 +864,23 @@ adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int
   if (wave == 4 && ft0 < ft1) stage(ft0, 0);
   for (int ft = ft0; ft < ft1; ++ft) {
     const int buf = (ft - ft0) & 1;
+#ifdef HYDRA_GRAM_STAMPS
+    unsigned long long a0, a1, a2 = 0, a3;
+    ADJ_STAMP(a0)
+#endif
     if (wave == 4) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();                      // tile ft has landed; the other buffer is free
+#ifdef HYDRA_GRAM_STAMPS
+    ADJ_STAMP(a1)
+#endif
     if (wave == 4) {
       if (ft + 1 < ft1) stage(ft + 1, buf ^ 1);
+#ifdef HYDRA_GRAM_STAMPS
+      ADJ_STAMP(a3)
+      if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && ft == ft0 + 2) {
+        g_adj_trace[4][0] = a0; g_adj_trace[4][1] = a1; g_adj_trace[4][2] = a3; g_adj_trace[4][3] = a3;
+      }
+#endif
       continue;
     }
     const f64x2* vb = s_v + (size_t)buf * nap * AB_SRC;
@@ -856,39 +898,57 @@ adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int
       const f64x2* zp = zr_ft + (size_t)adjbig_prefix(rb, nk) * 64;
       const double* zq = zs_ft + (size_t)adjbig_prefix(rb, nk) * 64;
       const f64x2* vp = vb + (size_t)(16 * rb + kr) * AB_SRC + lc;
+      auto load_step = [&](Group& o, int g, int u) {
+        o.z[u] = zp[(size_t)(4 * g + u) * 64];
+        o.s[u] = zq[(size_t)(4 * g + u) * 64];
+        o.v0[u] = vp[(size_t)(4 * g + u) * 4 * AB_SRC];
+        o.v1[u] = vp[(size_t)(4 * g + u) * 4 * AB_SRC + 16];
+      };
       auto load = [&](Group& o, int g) {
 #pragma unroll
+        for (int u = 0; u < 4; ++u) load_step(o, g, u);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      auto mma_step = [&](const Group& o, int u) {
+        const double s0v = o.v0[u].x + o.v0[u].y, s1v = o.v1[u].x + o.v1[u].y;
+        p1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].x, o.v0[u].x, p1[0], 0, 0, 0);
+        p1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].x, o.v1[u].x, p1[1], 0, 0, 0);
+        p2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].y, o.v0[u].y, p2[0], 0, 0, 0);
+        p2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].y, o.v1[u].y, p2[1], 0, 0, 0);
+        p3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.s[u], s0v, p3[0], 0, 0, 0);
+        p3[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.s[u], s1v, p3[1], 0, 0, 0);
+        __builtin_amdgcn_sched_barrier(0);
+      };
+      // One group multiplies while the operands of the group after next are read INTO ITS
+      // REGISTERS, k-step by k-step as they fall free: every read is 1.75 groups (42 matrix
+      // instructions, 2700 cycles) ahead of its use with two operand sets and no register moves
+      // (the Zc fragments come from L2, ~1500 cycles away).  No branch inside the loop body (a
+      // conditional use lets the compiler sink the reads next to it): reads past the row block's
+      // end repeat its last group and are not used.  What this does not cover is the start of a
+      // row block (two per (f,t) and wave: ~2000 cycles each until the first operands are there,
+      // and an epilogue of 8 LDS reads) -- carrying the two sets on into the next row block was
+      // tried: the operand sets then live through the epilogue, the compiler serialises its reads
+      // for want of registers (256: the stager shares a SIMD) and answers the joins with
+      // vmcnt(0): 2.6 ms against 2.1; prefetching only the next row block's first Zc fragments
+      // into 24 spare registers (across (f,t) too): 2.18 ms, no gain either.
+      auto mma_reload = [&](Group& o, int gnext) {
+#pragma unroll
         for (int u = 0; u < 4; ++u) {
-          o.z[u] = zp[(size_t)(4 * g + u) * 64];
-          o.s[u] = zq[(size_t)(4 * g + u) * 64];
-          o.v0[u] = vp[(size_t)(4 * g + u) * 4 * AB_SRC];
-          o.v1[u] = vp[(size_t)(4 * g + u) * 4 * AB_SRC + 16];
+          mma_step(o, u);
+          load_step(o, gnext, u);
+          __builtin_amdgcn_sched_barrier(0);
         }
-        __builtin_amdgcn_sched_barrier(0);     // the loads stay ahead of the other set's MFMAs
       };
       auto mma = [&](const Group& o) {
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          const double s0v = o.v0[u].x + o.v0[u].y, s1v = o.v1[u].x + o.v1[u].y;
-          p1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].x, o.v0[u].x, p1[0], 0, 0, 0);
-          p1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].x, o.v1[u].x, p1[1], 0, 0, 0);
-          p2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].y, o.v0[u].y, p2[0], 0, 0, 0);
-          p2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.z[u].y, o.v1[u].y, p2[1], 0, 0, 0);
-          p3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.s[u], s0v, p3[0], 0, 0, 0);
-          p3[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(o.s[u], s1v, p3[1], 0, 0, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
+        for (int u = 0; u < 4; ++u) mma_step(o, u);
       };
-      // two operand sets in turn: group g + 1 loads while group g multiplies (no register moves)
       Group ga, gb;
       load(ga, 0);
-      // (no branch inside the loop body: a conditional use lets the compiler sink the loads next
-      // to it; for an even group count the last load of ga is unused)
+      load(gb, min(1, ng - 1));
       for (int g = 0; g + 1 < ng; g += 2) {
-        load(gb, g + 1);
-        mma(ga);
-        load(ga, min(g + 2, ng - 1));
-        mma(gb);
+        mma_reload(ga, min(g + 2, ng - 1));
+        mma_reload(gb, min(g + 3, ng - 1));
       }
       if (ng & 1) mma(ga);
       // Re(V_i conj(W_i)) for the rows this lane holds: antenna 16 rb + kr + 4 g
@@ -904,8 +964,17 @@ adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int
     };
     for (int k = wave; 2 * k < nr; k += 4) {
       row_block(k);
+#ifdef HYDRA_GRAM_STAMPS
+      if (k == wave) { ADJ_STAMP(a2) }
+#endif
       if (nr - 1 - k != k) row_block(nr - 1 - k);
     }
+#ifdef HYDRA_GRAM_STAMPS
+    ADJ_STAMP(a3)
+    if (blockIdx.x == 0 && blockIdx.y == 0 && lane == 0 && ft == ft0 + 2) {
+      g_adj_trace[wave][0] = a0; g_adj_trace[wave][1] = a1; g_adj_trace[wave][2] = a2; g_adj_trace[wave][3] = a3;
+    }
+#endif
   }
   __syncthreads();                         // everyone is done with the voltage tiles
   if (wave < 4) {
@@ -931,6 +1000,12 @@ static void adjoint_V_plan(int nft, int ns, int* nsplit, int* per) {
 }  // namespace hydra
 
 using namespace hydra;
+
+#ifdef HYDRA_GRAM_STAMPS
+extern "C" int hydra_debug_adj_trace(unsigned long long* out_host) {
+  return hipMemcpyFromSymbol(out_host, HIP_SYMBOL(g_adj_trace), sizeof(g_adj_trace)) == hipSuccess ? 0 : -3;
+}
+#endif
 
 extern "C" {
 

@@ -31,12 +31,22 @@ def run(nant, ns=3000, nf=30, nt=20, reps=5):
         _dev.call("hydra_adjoint_V", _dev.ptr(V), nf, nt, nant, ns, _dev.ptr(bl_i), _dev.ptr(bl_j),
                   nbl, _dev.ptr(z), 0, 0, _dev.ptr(out), _dev.ptr(ws), ws.numel(), _dev.stream_ptr())
 
+    big = 64 < nant <= 160
+    if big:
+        ws3 = _dev.workspace(_dev._lib.query("hydra_adjoint_V_antspace_workspace_bytes", nf, nt, nant,
+                                             nbl, ns))
+
+    def adj_big():
+        _dev.call("hydra_adjoint_V_antspace", _dev.ptr(V), nf, nt, nant, ns, _dev.ptr(bl_i),
+                  _dev.ptr(bl_j), nbl, _dev.ptr(z), 0, 0, _dev.ptr(out), _dev.ptr(ws3), ws3.numel(),
+                  _dev.stream_ptr())
+
     def app():
         _dev.call("hydra_apply_V", _dev.ptr(V), nf, nt, nant, ns, _dev.ptr(bl_i), _dev.ptr(bl_j),
                   nbl, _dev.ptr(x), 0, _dev.ptr(vis), _dev.ptr(ws2), ws2.numel(), _dev.stream_ptr())
 
     res = {}
-    for name, fn in (("adjoint", adj), ("apply", app)):
+    for name, fn in (("adjoint", adj_big if big else adj), ("apply", app)):
         fn()
         torch.cuda.synchronize()
         t0 = time.perf_counter()
@@ -50,6 +60,30 @@ def run(nant, ns=3000, nf=30, nt=20, reps=5):
           flush=True)
 
 
+def trace():
+    """per-wave timeline of adjoint_V_big_kernel (stamped build: make -C hydra_amd/csrc stamps,
+    HYDRA_HIP_LIBRARY=hydra_amd/libhydra_hip_stamps.so)"""
+    import ctypes
+    from hydra_amd import _lib
+    lib = _lib.load()
+    if not hasattr(lib, "hydra_debug_adj_trace"):
+        return
+    tr = (ctypes.c_ulonglong * 64)()
+    if lib.hydra_debug_adj_trace(tr) != 0:
+        return
+    t = np.array(list(tr), dtype=np.int64).reshape(8, 8)[:5, :4]
+    t0 = t[:, 0].min()
+    print("adjoint_V_big_kernel, workgroup 0, third (f,t): cycles from the first barrier arrival")
+    print("  wave  at-barrier  past-barrier  first-row-block-done  all-done")
+    for w in range(5):
+        r = t[w] - t0
+        print(f"  {w:4d}  {r[0]:10d}  {r[1]:12d}  {r[2]:20d}  {r[3]:8d}")
+
+
 if __name__ == "__main__":
+    # sizes: ADJ_NS / ADJ_NF / ADJ_NT (config 3 at one LST block: 12288 / 128 / 1)
+    kw = dict(ns=int(os.environ.get("ADJ_NS", 3000)), nf=int(os.environ.get("ADJ_NF", 30)),
+              nt=int(os.environ.get("ADJ_NT", 20)))
     for n in [int(a) for a in sys.argv[1:]] or [40, 56, 64]:
-        run(n)
+        run(n, **kw)
+    trace()
