@@ -645,32 +645,34 @@ ufactor_kernel(const f64x2* __restrict__ gains, const double* __restrict__ wft, 
   f[(size_t)ft * fstride + nant] = sqrt(c4);
 }
 
+// One workgroup streams one antenna row of one (f,t) -- Ns contiguous complex values in, the same
+// out -- eight 16-byte loads in flight per lane.  (With a workgroup per 256 sources walking the
+// antennas, 37 separate 4-KiB streams each, the pass ran at 4.9 TB/s.)
 __global__ void __launch_bounds__(256)
 uscale_kernel(const f64x2* __restrict__ V, const double* __restrict__ f, int fstride, int nft,
               int nant, int nantp, int ns, int same_beam, f64x2* __restrict__ U) {
-  int s = blockIdx.x * blockDim.x + threadIdx.x;
-  if (s >= ns) return;
-  for (int ft = blockIdx.y; ft < nft; ft += gridDim.y) {   // grid.y is capped at 65535
-    const double* fr = f + (size_t)ft * fstride;           // uniform: scalar loads
-    const f64x2* vp = V + (size_t)ft * nant * ns + s;
-    f64x2* up = U + (size_t)ft * nantp * ns + s;
-    const f64x2 v0 = vp[0];
-    for (int a0 = 0; a0 < nant; a0 += 8) {                 // 8 loads in flight per lane
+  const int a = blockIdx.x;                                  // row of U
+  for (int ft = blockIdx.y; ft < nft; ft += gridDim.y) {     // grid.y is capped at 65535
+    f64x2* up = U + ((size_t)ft * nantp + a) * ns;
+    const int kind = a < nant ? 1 : (same_beam && a == nant ? 2 : 0);
+    if (kind == 0) {
+      for (int s = threadIdx.x; s < ns; s += 256) up[s] = f64x2{0.0, 0.0};
+      continue;
+    }
+    const double fa = f[(size_t)ft * fstride + a];           // uniform: scalar load
+    const f64x2* vp = V + ((size_t)ft * nant + (kind == 1 ? a : 0)) * ns;
+    for (int s0 = threadIdx.x; s0 < ns; s0 += 8 * 256) {
       f64x2 v[8];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (a0 + q < nant) v[q] = vp[(size_t)(a0 + q) * ns];
+      for (int q = 0; q < 8; ++q) v[q] = vp[min(s0 + q * 256, ns - 1)];
 #pragma unroll
-      for (int q = 0; q < 8; ++q)
-        if (a0 + q < nant) {
-          double fa = fr[a0 + q];
-          up[(size_t)(a0 + q) * ns] = f64x2{v[q].x * fa, v[q].y * fa};
-        }
+      for (int q = 0; q < 8; ++q) {
+        const int s = s0 + q * 256;
+        if (s < ns)
+          up[s] = kind == 1 ? f64x2{v[q].x * fa, v[q].y * fa}
+                            : f64x2{fa * (v[q].x * v[q].x + v[q].y * v[q].y), 0.0};
+      }
     }
-    for (int a = nant; a < nantp; ++a)
-      up[(size_t)a * ns] = (same_beam && a == nant)
-                               ? f64x2{fr[nant] * (v0.x * v0.x + v0.y * v0.y), 0.0}
-                               : f64x2{0.0, 0.0};
   }
 }
 
@@ -1396,7 +1398,7 @@ int hydra_gram_uniform(const double* V, int nf, int nt, int nant, int ns, const 
   ufactor_kernel<<<(nft + 255) / 256, 256, 0, st>>>(reinterpret_cast<const f64x2*>(gains), w_ft, nft,
                                                     nant, nant + 1, ftab);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform(factors)");
-  dim3 ugrid((ns + 255) / 256, std::min(nft, 65535));
+  dim3 ugrid(nantp, std::min(nft, 65535));
   uscale_kernel<<<ugrid, 256, 0, st>>>(reinterpret_cast<const f64x2*>(V), ftab, nant + 1, nft, nant,
                                        nantp, ns, same_beam, U);
   HYDRA_CHECK_LAUNCH("hydra_gram_uniform(scale)");
