@@ -327,3 +327,44 @@ def test_healpix_beam_oracle_interpolates_linearly_in_frequency():
     assert out.shape == (1, 1, 3, 7)
     assert np.allclose(out[0, 0, 0], maps[0, :7]) and np.allclose(out[0, 0, 2], maps[1, :7])
     assert np.allclose(out[0, 0, 1], 0.75 * maps[0, :7] + 0.25 * maps[1, :7])
+
+
+def test_polybeam_known_answers():
+    """hera_sim PolyBeam as restated in oracle/beams.py (hydra/example.py:143-168): unit response
+    at zenith whatever the coefficients and the channel; a pure T_1 beam is (1 - 2 sin za)^2; the
+    spectral index only rescales the zenith angle, za -> za / (nu / nu_ref)^index."""
+    rng = np.random.RandomState(3)
+    coeffs = rng.randn(9)
+    pb = beams.PolyBeam(coeffs, spectral_index=-0.7, ref_freq=1.0e8)
+    za = np.linspace(0.0, 1.2, 7)
+    freqs = np.array([0.8e8, 1.0e8, 1.3e8])
+    r = pb.compute_response(az_array=np.zeros_like(za), za_array=za, freq_array=freqs)[0, 0]
+    assert r.shape == (3, 7)
+    assert np.allclose(r[:, 0], 1.0, atol=1e-14)
+    t1 = beams.PolyBeam([0.0, 1.0], spectral_index=0.0, ref_freq=1.0e8)
+    r1 = t1.compute_response(az_array=np.zeros_like(za), za_array=za, freq_array=freqs[:1])[0, 0, 0]
+    assert np.allclose(r1, (1.0 - 2.0 * np.sin(za)) ** 2, atol=1e-14)
+    scale = (freqs / 1.0e8) ** -0.7
+    ref = beams.PolyBeam(coeffs, spectral_index=0.0, ref_freq=1.0e8)
+    for k in range(3):
+        rk = ref.compute_response(az_array=np.zeros_like(za), za_array=za / scale[k],
+                                  freq_array=np.array([1.0e8]))[0, 0, 0]
+        assert np.allclose(r[k], rk, rtol=1e-13, atol=1e-15)
+
+
+def test_sidereal_invariance_and_transit_symmetry():
+    """Topocentric coordinates depend on (ra - lst) only, and a source is mirrored east-west
+    about its transit: e(-h) = -e(h), n and up even in the hour angle h (matvis
+    eci_to_enu_matrix / point_source_crd_eq as restated in oracle/geometry.py)."""
+    rng = np.random.RandomState(4)
+    ra, dec = rng.uniform(0, 2 * np.pi, 20), rng.uniform(-1.2, 0.6, 20)
+    lst, shift = 1.1, 0.37
+    a = geometry.eci_to_enu_matrix(lst, LAT) @ geometry.point_source_crd_eq(ra, dec)
+    b = geometry.eci_to_enu_matrix(lst + shift, LAT) @ geometry.point_source_crd_eq(ra + shift, dec)
+    assert np.allclose(a, b, atol=1e-14)
+    h = rng.uniform(0, 1.0, 20)
+    m = geometry.eci_to_enu_matrix(lst, LAT)
+    before = m @ geometry.point_source_crd_eq(lst + h, dec)     # ra > lst: east
+    after = m @ geometry.point_source_crd_eq(lst - h, dec)
+    assert np.allclose(before[0], -after[0], atol=1e-14) and np.all(before[0] >= 0)
+    assert np.allclose(before[1:], after[1:], atol=1e-14)
