@@ -412,6 +412,22 @@ def case_gainmpi(comm):
                                     use_norm_tol=True, abs_tol=1e-11, maxiters=500, return_iters=True)
     assert 0 < iters < 500
     assert np.max(np.abs(x2.cpu().numpy() - x_ref)) <= 1e-8 * np.max(np.abs(x_ref))
+    # the one-pass form on each rank's channels: same right-hand side on every rank, same operator
+    gains = 1.0 + 0.2 * (rng.randn(nant, nf, nt) + 1j * rng.randn(nant, nf, nt))
+    data = rng.randn(*shape) + 1j * rng.randn(*shape)
+    ggv = hy.utils.apply_gains(mv, gains, ants, antpairs, inline=False)
+    b3 = gs.construct_rhs_mpi(None, data - ggv, w, ps, A_real, A_imag, ggv, Fb, omega_y=om_y,
+                              omega_r=om_r)
+    op3 = gs.GainOperator(w, ps, A_real, A_imag, ggv, Fb)
+    b4, op4 = gs.prepare_sample(comm, data[:, f], mvk, gains[:, f], wk, ps, A_real, A_imag, Fk,
+                                omega_y=oy, omega_r=ork)
+    assert op4._mv is None                                   # hydra_gain_prepare_stream ran
+    assert np.max(np.abs(b4 - b3)) <= 1e-12 * np.max(np.abs(b3))
+    t = op4.local(torch.as_tensor(v, device=dev))
+    comm.allreduce_(t)
+    y4 = (torch.as_tensor(v, device=dev) + t).cpu().numpy()
+    y3 = op3.apply(v)
+    assert np.max(np.abs(y4 - y3)) <= 1e-12 * np.max(np.abs(y3))
     comm.barrier()
 
 
