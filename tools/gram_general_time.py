@@ -21,7 +21,7 @@ nant, nbl = len(inp["ant_pos"]), len(inp["antpairs"])
 dev = _dev.device()
 gains = torch.as_tensor(inp["g0"], device=dev)[:, None, None].expand(nant, nf, nt).contiguous()
 w = torch.full((nbl, nf, nt), 400.0, dtype=torch.float64, device=dev)
-fac.allow_uniform = False
+fac.allow_uniform = os.environ.get("GRAM_CLOSED", "0") == "1"   # 1: time the closed-form path
 G = fac.gram(gains, w)
 torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
