@@ -33,6 +33,9 @@ __device__ unsigned long long g_stamps[8];
 // per-wave timeline of workgroup 0's third (f,t): [wave][barrier-1 arrival, after barrier 1,
 // DMA landed, after barrier 2, loop end]
 __device__ unsigned long long g_trace[8][8];
+#ifndef HYDRA_STAMP_BLOCK
+#define HYDRA_STAMP_BLOCK 0   // the fused kernel's stamped workgroup (config 2: 0 = a diagonal tile, 8 = a full one)
+#endif
 #define STAMP(var)                                                                       \
   __builtin_amdgcn_sched_barrier(0);                                                     \
   asm volatile("s_memtime %0\n\ts_waitcnt lgkmcnt(0)" : "=s"(var)::"memory");           \
@@ -111,8 +114,10 @@ struct Frag {
 // apart with sched_barrier: (1) issue the loads of step k+1, (2) the 2 MI NI back-to-back MFMAs of step
 // k, which cover the load latency, (3) one batch of VALU turning the loaded values into the
 // operands of step k+1.
-template <int MI, int NI, class P>
-__device__ __forceinline__ void mfma_pipeline(P& prod, int nsteps, f64x4 (&acc)[MI][NI]) {
+// DIAG: a tile on the Gram's diagonal; its `lower` waves skip the blocks above their own diagonal.
+template <int MI, int NI, bool DIAG, class P>
+__device__ __forceinline__ void mfma_pipeline(P& prod, int nsteps, f64x4 (&acc)[MI][NI],
+                                              bool lower = false) {
   Frag<MI, NI> cur;
   prod.issue();
   prod.finish(cur);
@@ -130,10 +135,39 @@ __device__ __forceinline__ void mfma_pipeline(P& prod, int nsteps, f64x4 (&acc)[
     __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
     for (int g = 0; g < MI; ++g) {
+      if (DIAG) break;
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[g][ni] = mfma(cur.are[g], cur.bre[ni], acc[g][ni]);
 #pragma unroll
       for (int ni = 0; ni < NI; ++ni) acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
+    }
+    if (DIAG) {
+      // all real-part products, then all imaginary-part ones (the same order per accumulator):
+      // with a row of one or two blocks the two would otherwise follow each other directly and
+      // wait out the instruction's latency; the blocks above the diagonal under one uniform
+      // branch each (two pipelines, one per kind of wave, spilled 345 registers)
+#pragma unroll
+      for (int g = 0; g < MI; ++g)
+#pragma unroll
+        for (int ni = 0; ni <= g && ni < NI; ++ni)
+          acc[g][ni] = mfma(cur.are[g], cur.bre[ni], acc[g][ni]);
+      if (!lower) {
+#pragma unroll
+        for (int g = 0; g < MI; ++g)
+#pragma unroll
+          for (int ni = g + 1; ni < NI; ++ni) acc[g][ni] = mfma(cur.are[g], cur.bre[ni], acc[g][ni]);
+      }
+#pragma unroll
+      for (int g = 0; g < MI; ++g)
+#pragma unroll
+        for (int ni = 0; ni <= g && ni < NI; ++ni)
+          acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
+      if (!lower) {
+#pragma unroll
+        for (int g = 0; g < MI; ++g)
+#pragma unroll
+          for (int ni = g + 1; ni < NI; ++ni) acc[g][ni] = mfma(cur.aim[g], cur.bim[ni], acc[g][ni]);
+      }
     }
     __builtin_amdgcn_sched_barrier(0);
 #ifdef HYDRA_GRAM_STAMPS_INNER
@@ -419,13 +453,14 @@ struct FusedProducer {
   const double* s_w;
   const uint32_t* s_info;
   int nrows, kr, offA, offB, grp;
+  int ksub, kpar;       // this wave takes k-steps ksub * (its group's n-th) + kpar  (1, 0: all)
   int n_next;           // ordinal (within the group) of the k-step whose row info is fetched next
   uint32_t info_next;   // packed LDS rows of the step after the one being issued
   double w_next, w;
   f64x2 ai[MI], aj[MI], bi[NI], bj[NI];
 
   __device__ __forceinline__ void prefetch_info() {
-    int r = 4 * KSplit<NG, KSPLIT_M>::step(grp, n_next) + kr;
+    int r = 4 * (ksub * KSplit<NG, KSPLIT_M>::step(grp, n_next) + kpar) + kr;
     ++n_next;
     bool valid = r < nrows;
     info_next = s_info[valid ? r : 0];
@@ -486,7 +521,11 @@ struct FusedProducer {
 // group as 2 x 2 (a 128 x 128 tile), or 5 x 2 with the waves side by side (80 x 128) for the last
 // row band when at most 80 of its 128 rows exist (config 2: 2000 = 15 x 128 + 80 -- 16 of the 136
 // tiles then cost 20 instead of 32 matrix instructions per k-step).
-template <int NG, int MI, int NI>
+// DIAG (a 128 x 128 tile on the Gram's diagonal): the upper right wave tile is never read, so its
+// wave (1) joins wave 2 on the lower left one -- odd and even k-steps, summed through LDS at the
+// end -- and waves 0 and 3 compute only the 10 blocks on and below their own diagonal: 20, 16, 16
+// and 20 matrix instructions per k-step on the four SIMDs instead of 32 on three and none on one.
+template <int NG, int MI, int NI, bool DIAG>
 __device__ __forceinline__ void
 fused_tile(const f64x2* __restrict__ V, int nft, int nant, int ns,
            const double* __restrict__ wrow, int nbl,
@@ -498,11 +537,11 @@ fused_tile(const f64x2* __restrict__ V, int nft, int nant, int ns,
   double* s_sw = reinterpret_cast<double*>(smem + (size_t)max_lds_rows * 256 * 16);
   uint32_t* s_info = reinterpret_cast<uint32_t*>(s_sw + max_seg_rows);
   constexpr int NTHREADS = 256 * NG;
-  static_assert((MI == 4 && NI == 4) || (MI == 5 && NI == 2), "wave tile shapes");
+  static_assert((MI == 4 && NI == 4) || (MI == 5 && NI == 2 && !DIAG), "wave tile shapes");
 
   int tid = threadIdx.x, lane = tid & 63, wave = (tid >> 6) & 3, grp = tid >> 8;
-  const int row0w = MI == 4 ? (wave >> 1) * 64 : 0;
-  const int col0w = MI == 4 ? (wave & 1) * 64 : wave * 32;
+  const int row0w = DIAG ? (wave == 0 ? 0 : 64) : MI == 4 ? (wave >> 1) * 64 : 0;
+  const int col0w = DIAG ? (wave == 3 ? 64 : 0) : MI == 4 ? (wave & 1) * 64 : wave * 32;
   int ft_begin = split * ft_per_split;
   int ft_end = ft_begin + ft_per_split;
   if (ft_end > nft) ft_end = nft;
@@ -527,6 +566,9 @@ fused_tile(const f64x2* __restrict__ V, int nft, int nant, int ns,
   const int kr = lane >> 4;
   const int offA = row0w + (lane & 15);
   const int offB = 128 + col0w + (lane & 15);
+  const bool lower = DIAG && (sq == 0 || sq == 3);     // wave-uniform
+  const int ksub = (DIAG && (sq == 1 || sq == 2)) ? 2 : 1;
+  const int kpar = (DIAG && sq == 1) ? 1 : 0;
 
   for (int ft = ft_begin; ft < ft_end; ++ft) {
     const f64x2* vft = V + (size_t)ft * nant * ns;
@@ -564,18 +606,20 @@ fused_tile(const f64x2* __restrict__ V, int nft, int nant, int ns,
       __syncthreads();
 #ifdef HYDRA_GRAM_STAMPS
       STAMP(f1)
-      if (blockIdx.x == 0 && threadIdx.x == 0) g_stamps[0] += f1 - f0;
+      if (blockIdx.x == HYDRA_STAMP_BLOCK && threadIdx.x == 0) g_stamps[0] += f1 - f0;
 #endif
 
       FusedProducer<NG, MI, NI> prod;
       prod.s_u = s_u; prod.s_w = s_sw; prod.s_info = s_info;
       prod.nrows = nrows; prod.kr = kr; prod.offA = offA; prod.offB = offB;
       prod.grp = swave >> 2;
+      prod.ksub = ksub; prod.kpar = kpar;
       prod.start();
-      mfma_pipeline(prod, KSplit<NG, KSPLIT_M>::count(swave >> 2, (nrows + 3) / 4), acc);
+      const int nk = ((nrows + 3) / 4 - kpar + ksub - 1) / ksub;   // k-steps of this wave's tile share
+      mfma_pipeline<MI, NI, DIAG>(prod, KSplit<NG, KSPLIT_M>::count(swave >> 2, nk), acc, lower);
 #ifdef HYDRA_GRAM_STAMPS
       STAMP(e5)
-      if (blockIdx.x == 0 && lane == 0 && ft == ft_begin + 2 && sg == 0) {
+      if (blockIdx.x == HYDRA_STAMP_BLOCK && lane == 0 && ft == ft_begin + 2 && sg == 0) {
         g_trace[swave][0] = f0; g_trace[swave][1] = e1; g_trace[swave][2] = e2;
         g_trace[swave][3] = f1; g_trace[swave][4] = e5;
       }
@@ -604,7 +648,29 @@ fused_tile(const f64x2* __restrict__ V, int nft, int nant, int ns,
           for (int g = 0; g < 4; ++g) acc[i][j][g] += s_red[((i * NI + j) * 4 + g) * 256 + scid];
     }
   }
-  if (grp == 0)
+  if (DIAG) {
+    // wave 1 -> LDS -> wave 2 (group 0 holds the groups' sum by now)
+    double* s_red = reinterpret_cast<double*>(smem);
+    __syncthreads();
+    if (grp == 0 && wave == 1) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) s_red[((i * NI + j) * 4 + g) * 64 + lane] = acc[i][j][g];
+    }
+    __syncthreads();
+    if (grp == 0 && wave == 2) {
+#pragma unroll
+      for (int i = 0; i < MI; ++i)
+#pragma unroll
+        for (int j = 0; j < NI; ++j)
+#pragma unroll
+          for (int g = 0; g < 4; ++g) acc[i][j][g] += s_red[((i * NI + j) * 4 + g) * 64 + lane];
+    }
+  }
+  if (grp == 0 && !(DIAG && wave == 1))
     store_blocks<MI, NI>(slabs + ((size_t)split * ntiles + tile) * TILE_ELEMS, acc, row0w, col0w,
                          lane);
 #ifdef HYDRA_GRAM_STAMPS
@@ -622,17 +688,49 @@ gram_fused_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns,
                   const int32_t* __restrict__ seg, int nseg, const int32_t* __restrict__ rowtab,
                   int max_lds_rows, int max_seg_rows, int ntiles, int ft_per_split,
                   double* __restrict__ slabs) {
-  int tile, split;
-  block_work(blockIdx.x, ntiles, &tile, &split);
-  int ti, tj;
-  tile_of(tile, &ti, &tj);
+  // Workgroup -> (tile, split).  The three kinds of tile differ in cost (measured per (f,t) at
+  // config 2: full 1, diagonal 0.68, short last band 0.67), and workgroups are handed out in index
+  // order, round robin over the XCDs: with the kinds interleaved a CU that finishes a cheap tile
+  // waits for the XCD whose turn it is.  So the kinds are queued one after the other, the dearest
+  // first (which also shortens the tail); inside a kind the order is block_work's -- an XCD walks
+  // the tiles of one (f,t) range after the other.
+  const int nt1 = (ns + TS - 1) / TS;
   const int last_rows = ns % TS;
-  if (last_rows != 0 && last_rows <= 80 && ti == (ns - 1) / TS)   // uniform over the workgroup
-    fused_tile<NG, 5, 2>(V, nft, nant, ns, wrow, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows,
-                         ntiles, ft_per_split, slabs, tile, split, ti, tj);
+  const bool short_band = last_rows != 0 && last_rows <= 80;
+  int tile, split, ti, tj, kind;   // kind 0 full, 1 diagonal, 2 short last band
+  if (gridDim.x == (unsigned)ntiles) {
+    tile = blockIdx.x; split = 0;
+    tile_of(tile, &ti, &tj);
+    kind = (short_band && ti == nt1 - 1) ? 2 : (ti == tj ? 1 : 0);
+  } else {
+    const int xcd = blockIdx.x & 7, spx = gridDim.x / (8 * ntiles);   // splits per XCD
+    int q = blockIdx.x >> 3;
+    const int nsq = short_band ? nt1 - 1 : nt1;        // rows of the square-tile part
+    const int n_full = nsq * (nsq - 1) / 2, n_diag = nsq;
+    int c;
+    if (q < n_full * spx) {
+      kind = 0; c = q % n_full; split = (q / n_full) * 8 + xcd;
+      tile_of(c, &ti, &tj);                            // strictly lower: (a, b), b <= a  ->  (a + 1, b)
+      ti += 1;
+    } else if ((q -= n_full * spx) < n_diag * spx) {
+      kind = 1; c = q % n_diag; split = (q / n_diag) * 8 + xcd;
+      ti = tj = c;
+    } else {
+      q -= n_diag * spx;
+      kind = 2; c = q % nt1; split = (q / nt1) * 8 + xcd;
+      ti = nt1 - 1; tj = c;
+    }
+    tile = ti * (ti + 1) / 2 + tj;
+  }
+  if (kind == 2)   // uniform over the workgroup
+    fused_tile<NG, 5, 2, false>(V, nft, nant, ns, wrow, nbl, seg, nseg, rowtab, max_lds_rows,
+                                max_seg_rows, ntiles, ft_per_split, slabs, tile, split, ti, tj);
+  else if (kind == 1)
+    fused_tile<NG, 4, 4, true>(V, nft, nant, ns, wrow, nbl, seg, nseg, rowtab, max_lds_rows,
+                               max_seg_rows, ntiles, ft_per_split, slabs, tile, split, ti, tj);
   else
-    fused_tile<NG, 4, 4>(V, nft, nant, ns, wrow, nbl, seg, nseg, rowtab, max_lds_rows, max_seg_rows,
-                         ntiles, ft_per_split, slabs, tile, split, ti, tj);
+    fused_tile<NG, 4, 4, false>(V, nft, nant, ns, wrow, nbl, seg, nseg, rowtab, max_lds_rows,
+                                max_seg_rows, ntiles, ft_per_split, slabs, tile, split, ti, tj);
 }
 
 
@@ -1369,6 +1467,7 @@ int hydra_gram_fused(const double* V, int nf, int nt, int nant, int ns, const do
   // two wave groups per workgroup when LDS leaves room for a single workgroup per CU
   bool two_groups = lds > 80 * 1024;
   if (two_groups) lds = std::max<size_t>(lds, (size_t)TILE_ELEMS * sizeof(double));
+  lds = std::max<size_t>(lds, 64 * 64 * sizeof(double));   // diagonal tiles: wave 1 -> wave 2
   const void* kfn = two_groups ? reinterpret_cast<const void*>(&gram_fused_kernel<2>)
                                : reinterpret_cast<const void*>(&gram_fused_kernel<1>);
   hipError_t e = hipFuncSetAttribute(kfn, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
