@@ -178,9 +178,24 @@ double time_ms(F f) {
   return ms;
 }
 
-int main() {
+int main(int argc, char** argv) {
   double* out; hipMalloc(&out, sizeof(double) * 256 * 256 * 16);
   const int iters = 20000;
+  if (argc > 1) {
+    // sustained clock: the same pure-MFMA kernel for ~argv[1] x 17 ms in one launch (the short
+    // sweeps below end before the power management settles)
+    int mult = atoi(argv[1]);
+    for (int rep = 0; rep < 3; ++rep) {
+      int grid = 256 * 2;
+      double ms = time_ms([&] { k_tile2<<<grid, 256>>>(out, iters * 2 * mult, 1.2345678901234567, 0.3712345678901234, 1); });
+      double fl = (double)grid * 4 * iters * 16 * 2048.0 * mult;
+      unsigned long long cyc[2];
+      hipMemcpyFromSymbol(cyc, HIP_SYMBOL(g_cycles), sizeof(cyc));
+      printf("sustained (2 blocks/CU, 2x4 tile, random data) x%d: %.1f ms %.1f TFLOP/s | %.1f cyc/MFMA per wave, %.2f GHz\n",
+             mult, ms, fl / ms / 1e9, (double)cyc[0] / (iters * 16.0 * mult), (double)cyc[0] / cyc[1] * 0.1);
+    }
+    return 0;
+  }
   // occupancy sweep with a small accumulator set (nacc=2: <=64 VGPR -> up to 8 waves/SIMD)
   for (int wpc = 1; wpc <= 8; ++wpc) {
     int grid = 256 * wpc;
