@@ -248,7 +248,8 @@ def _gcr_inputs(nbl, nant, nf, nt, ns, seed, uniform_noise=False):
 @pytest.mark.parametrize("hex_spec,ns,nf,nt", [((3, 4), 100, 4, 5), ((4, 7), 150, 2, 3),
                                                ((5, 9), 200, 2, 2), ((3, 4), 100, 16, 20),
                                                ((3, 4), 60, 2, 3), ((3, 4), 208, 3, 2),
-                                               ((3, 4), 209, 2, 2)])
+                                               ((3, 4), 209, 2, 2), ((2, 3), 150, 2, 2),
+                                               ((2, 3), 300, 1, 3)])
 def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, nf, nt):
     """End to end on the simulator's own operator: fused (factored) path == materialised HIP
     path == oracle, for one-segment (10, 37 antennas) and multi-segment (61 antennas) tables;
@@ -256,7 +257,9 @@ def test_factored_system_matches_oracle_and_materialised(hy, orc, hex_spec, ns, 
     its exact size: hex (3,4) = 10 antennas / 45 baselines, 100 sources, 16 freqs, 20 times.
     Last row band of the tile grid: 60 = one 80-row tile on the diagonal, 150 / 200 / 208 = an
     80-row band under full tiles (22, 72, exactly 80 rows; one and two wave groups), 209 = 81
-    rows, a full tile again."""
+    rows, a full tile again.  hex (2,3) = 7 antennas: the staged voltages alone (28 KiB) are smaller
+    than the 32 KiB the diagonal tiles' hand-over needs; 150 sources there = no full tile at all,
+    300 = full, diagonal and short-band tiles in one launch."""
     ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(hex_spec, ns, nf, nt, seed=5)
     nant, nbl = len(ant_pos), len(antpairs)
     ants = np.array(list(ant_pos.keys()))
