@@ -30,36 +30,60 @@ gain_weights_kernel(const f64x2* __restrict__ mv, const double* __restrict__ w, 
 }
 
 // g[v,a,ft] = sum_m F[m,ft] * s_m (xre[v,a,m] + i xim[v,a,m]);  x (nvec, 2*nant*nmodes)
+// A thread owns one (f,t) sample and GF_AB antennas: the basis values it loads (GF_MC modes at a
+// time, in registers) serve all of them; the scaled mode amplitudes of the workgroup's antennas
+// are staged in LDS and read as broadcasts.  (One thread per antenna and sample made every
+// antenna re-read the whole basis through L2 -- 24 us per application at config 4 -- and with
+// the amplitudes fetched by scalar loads inside the loop the kernel waited on those: 38 us.)
+// Modes are summed in order.
+constexpr int GF_AB = 8, GF_MC = 16;
 __global__ void __launch_bounds__(256)
 gain_basis_fwd_kernel(const double* __restrict__ x, const f64x2* __restrict__ F,
                       const double* __restrict__ s, int nant, int nmodes, int nft,
                       f64x2* __restrict__ g) {
-  int ft = blockIdx.x * blockDim.x + threadIdx.x;
-  int a = blockIdx.y, v = blockIdx.z;
-  if (ft >= nft) return;
-  const double* xre = x + (size_t)v * 2 * nant * nmodes + (size_t)a * nmodes;
+  __shared__ f64x2 s_z[GF_AB][GF_MC];
+  const int ft = blockIdx.x * blockDim.x + threadIdx.x;
+  const int ftc = min(ft, nft - 1);
+  const int a0 = blockIdx.y * GF_AB, v = blockIdx.z;
+  const double* xre = x + (size_t)v * 2 * nant * nmodes;
   const double* xim = xre + (size_t)nant * nmodes;
-  f64x2 acc = {0.0, 0.0};
-  // 8 basis loads in flight per lane (clamped, unconditional): one load per trip left the kernel
-  // latency bound (24 us per application at config 4).  Same summation order.
-  for (int m0 = 0; m0 < nmodes; m0 += 8) {
-    f64x2 fv[8];
+  f64x2 acc[GF_AB];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) fv[u] = F[(size_t)min(m0 + u, nmodes - 1) * nft + ft];
+  for (int q = 0; q < GF_AB; ++q) acc[q] = f64x2{0.0, 0.0};
+  for (int m0 = 0; m0 < nmodes; m0 += GF_MC) {
+    f64x2 fv[GF_MC];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int m = m0 + u;
+    for (int u = 0; u < GF_MC; ++u) fv[u] = F[(size_t)min(m0 + u, nmodes - 1) * nft + ftc];
+    __syncthreads();
+    if (threadIdx.x < GF_AB * GF_MC) {
+      const int q = threadIdx.x / GF_MC, u = threadIdx.x % GF_MC, m = m0 + u;
+      f64x2 z = {0.0, 0.0};
       if (m < nmodes) {
-        double sm = s ? s[m] : 1.0;
-        f64x2 z = {sm * xre[m], sm * xim[m]};
-        f64x2 r = cmul(fv[u], z);
-        acc.x += r.x;
-        acc.y += r.y;
+        const size_t o = (size_t)min(a0 + q, nant - 1) * nmodes + m;
+        const double sm = s ? s[m] : 1.0;
+        z = f64x2{sm * xre[o], sm * xim[o]};
       }
+      s_z[q][u] = z;      // modes past the end contribute exact zeros
     }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < GF_MC; ++u)
+#pragma unroll
+      for (int q = 0; q < GF_AB; ++q) {      // four FMAs per complex multiply-add
+        const f64x2 z = s_z[q][u];
+        acc[q].x = __builtin_fma(fv[u].x, z.x, acc[q].x);
+        acc[q].x = __builtin_fma(-fv[u].y, z.y, acc[q].x);
+        acc[q].y = __builtin_fma(fv[u].x, z.y, acc[q].y);
+        acc[q].y = __builtin_fma(fv[u].y, z.x, acc[q].y);
+      }
   }
-  g[((size_t)v * nant + a) * nft + ft] = acc;
+  if (ft < nft) {
+#pragma unroll
+    for (int q = 0; q < GF_AB; ++q)
+      if (a0 + q < nant) g[((size_t)v * nant + a0 + q) * nft + ft] = acc[q];
+  }
 }
+static_assert(GF_AB * GF_MC <= 256, "at most one amplitude per thread");
 
 // y[v,a,ft] = g[v,a,ft] sum_b W[b,ft] + conj( sum_b W[b,ft] g[v,other(b),ft] ), b in adj(a)
 template <int NV>
@@ -694,79 +718,97 @@ gain_proj_conj_kernel(const f64x2* __restrict__ v, const f64x2* __restrict__ mv,
 
 // out[v, a*nmodes+m] = Re, out[v, nant*nmodes + a*nmodes+m] = Im of
 //   s_m sum_ft conj(F[m,ft]) y[v,a,ft]  (+ add[v, same index] if add != NULL)
-// One workgroup per (antenna, vector): the y row is staged in LDS in chunks and every wave
-// owns the modes m = wave, wave+4, ...; lanes stride over (f,t); fixed-order wave reduction.
-constexpr int GB_CHUNK = 2048;
-__global__ void __launch_bounds__(256)
+// One workgroup of 16 waves per pair of antennas (and vector).  A lane owns (f,t) samples -- wave
+// w the 64-sample pieces w, w + 16, ... -- and keeps the sums of GA_AB antennas x GA_MC modes in
+// registers, so every basis value it loads (coalesced, once per pass) serves both antennas and no
+// lane waits on another until the end of the pass; four waves per SIMD cover each other's load
+// latency.  Then the lanes' sums are added through LDS, 8 values at a time (each lane writes its
+// 8, lane (i, grp) adds 8 rows of column i, three shuffles join the eight groups), and the
+// sixteen waves' sums in wave order.  The order is fixed: same bits every run.
+// (Before: one workgroup per antenna, a wave per mode, 32 basis loads in flight per lane --
+// 54 us per application at config 4, one dependent wave reduction per mode.)
+constexpr int GA_AB = 2, GA_MC = 8, GA_WAVES = 16;
+constexpr int GA_NVAL = GA_AB * GA_MC * 2;
+__global__ void __launch_bounds__(64 * GA_WAVES)
 gain_basis_adj_kernel(const f64x2* __restrict__ y, const f64x2* __restrict__ F,
                       const double* __restrict__ s, const double* __restrict__ add, int nant,
                       int nmodes, int nft, double* __restrict__ out) {
-  __shared__ f64x2 s_y[GB_CHUNK];
-  int a = blockIdx.x, v = blockIdx.y;
-  int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const f64x2* yrow = y + ((size_t)v * nant + a) * nft;
-  size_t obase = (size_t)v * 2 * nant * nmodes + (size_t)a * nmodes;
-  for (int m0 = 0; m0 < nmodes; m0 += 4 * 8) {
-    f64x2 acc[8];
+  __shared__ double s_tr[GA_WAVES][64][9];
+  __shared__ double s_part[GA_WAVES][GA_NVAL];
+  const int a0 = blockIdx.x * GA_AB, v = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const f64x2* yrow[GA_AB];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) acc[q] = f64x2{0.0, 0.0};
-    for (int c0 = 0; c0 < nft; c0 += GB_CHUNK) {
-      int cn = min(GB_CHUNK, nft - c0);
-      __syncthreads();
-      for (int k = threadIdx.x; k < cn; k += 256) s_y[k] = yrow[c0 + k];
-      __syncthreads();
-      // Four modes at a time, 8 basis loads each: 32 loads in flight per lane (unconditional,
-      // clamped).  One dependent load per trip left this kernel at 0.12 ms per call, 8 in flight
-      // at 0.054 ms, still latency bound.  Same summation order per mode.
+  for (int q = 0; q < GA_AB; ++q) yrow[q] = y + ((size_t)v * nant + min(a0 + q, nant - 1)) * nft;
+  const size_t obase = (size_t)v * 2 * nant * nmodes;
+  for (int m0 = 0; m0 < nmodes; m0 += GA_MC) {
+    f64x2 acc[GA_AB][GA_MC];
 #pragma unroll
-      for (int qh = 0; qh < 8; qh += 4) {
-        if (m0 + qh * 4 + wave >= nmodes) continue;            // uniform per wave
-        for (int kb = lane; kb < cn; kb += 512) {
-          f64x2 fv[4][8];
+    for (int q = 0; q < GA_AB; ++q)
 #pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            const int m = min(m0 + (qh + qq) * 4 + wave, nmodes - 1);
-            const f64x2* fr = F + (size_t)m * nft + c0;
+      for (int mm = 0; mm < GA_MC; ++mm) acc[q][mm] = f64x2{0.0, 0.0};
+    for (int base = wave * 64; base < nft; base += GA_WAVES * 64) {
+      const int ft = base + lane, ftc = min(ft, nft - 1);
+      f64x2 yv[GA_AB];
 #pragma unroll
-            for (int u = 0; u < 8; ++u) fv[qq][u] = fr[min(kb + 64 * u, cn - 1)];
-          }
-          f64x2 yv[8];
-#pragma unroll
-          for (int u = 0; u < 8; ++u) yv[u] = s_y[min(kb + 64 * u, cn - 1)];
-#pragma unroll
-          for (int qq = 0; qq < 4; ++qq) {
-            if (m0 + (qh + qq) * 4 + wave < nmodes) {
-              f64x2 t = acc[qh + qq];
-#pragma unroll
-              for (int u = 0; u < 8; ++u) {
-                if (kb + 64 * u < cn) {
-                  f64x2 r = cmul_conj(fv[qq][u], yv[u]);
-                  t.x += r.x;
-                  t.y += r.y;
-                }
-              }
-              acc[qh + qq] = t;
-            }
-          }
-        }
+      for (int q = 0; q < GA_AB; ++q) {
+        yv[q] = yrow[q][ftc];
+        if (ft >= nft) yv[q] = f64x2{0.0, 0.0};
       }
-    }
+      f64x2 fv[GA_MC];
 #pragma unroll
-    for (int q = 0; q < 8; ++q) {
-      int m = m0 + q * 4 + wave;
-      if (m < nmodes) {  // uniform per wave
-        double re = wave_sum(acc[q].x), im = wave_sum(acc[q].y);
-        if (lane == 0) {
-          double sm = s ? s[m] : 1.0;
-          size_t o = obase + m;
-          size_t oi = o + (size_t)nant * nmodes;
-          out[o] = sm * re + (add ? add[o] : 0.0);
-          out[oi] = sm * im + (add ? add[oi] : 0.0);
+      for (int mm = 0; mm < GA_MC; ++mm) fv[mm] = F[(size_t)min(m0 + mm, nmodes - 1) * nft + ftc];
+#pragma unroll
+      for (int mm = 0; mm < GA_MC; ++mm)
+#pragma unroll
+        for (int q = 0; q < GA_AB; ++q) {    // conj(f) y, four FMAs
+          acc[q][mm].x = __builtin_fma(fv[mm].x, yv[q].x, acc[q][mm].x);
+          acc[q][mm].x = __builtin_fma(fv[mm].y, yv[q].y, acc[q][mm].x);
+          acc[q][mm].y = __builtin_fma(fv[mm].x, yv[q].y, acc[q][mm].y);
+          acc[q][mm].y = __builtin_fma(-fv[mm].y, yv[q].x, acc[q][mm].y);
         }
+    }
+    // lanes -> one sum per wave
+#pragma unroll
+    for (int b0 = 0; b0 < GA_NVAL; b0 += 8) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = b0 + i;
+        const f64x2 c = acc[idx / (2 * GA_MC)][(idx / 2) % GA_MC];
+        s_tr[wave][lane][i] = (idx & 1) ? c.y : c.x;
+      }
+      __syncthreads();
+      const int i = lane & 7, grp = lane >> 3;
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += s_tr[wave][grp * 8 + r][i];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (lane < 8) s_part[wave][b0 + lane] = t;
+    }
+    __syncthreads();
+    // waves -> out
+    if (tid < GA_AB * GA_MC) {
+      const int q = tid / GA_MC, mm = tid - q * GA_MC, m = m0 + mm;
+      if (m < nmodes && a0 + q < nant) {
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int w = 0; w < GA_WAVES; ++w) {
+          re += s_part[w][(q * GA_MC + mm) * 2];
+          im += s_part[w][(q * GA_MC + mm) * 2 + 1];
+        }
+        const double sm = s ? s[m] : 1.0;
+        const size_t o = obase + (size_t)(a0 + q) * nmodes + m;
+        const size_t oi = o + (size_t)nant * nmodes;
+        out[o] = sm * re + (add ? add[o] : 0.0);
+        out[oi] = sm * im + (add ? add[oi] : 0.0);
       }
     }
   }
 }
+static_assert(GA_NVAL % 8 == 0, "whole batches of 8 values");
 
 }  // namespace hydra
 
@@ -797,8 +839,9 @@ int hydra_gain_basis_fwd(const double* x, int nvec, int nant, int nmodes, int nf
                          const double* Fbasis, const double* pspec_sqrt, double* g, void* stream) {
   HYDRA_CHECK_ARG(x && Fbasis && g && nvec > 0 && nant > 0 && nmodes > 0 && nft > 0,
                   "hydra_gain_basis_fwd: bad arguments");
-  HYDRA_CHECK_ARG(nant <= 65535 && nvec <= 65535, "hydra_gain_basis_fwd: nant, nvec <= 65535");
-  dim3 grid((nft + 255) / 256, nant, nvec);
+  HYDRA_CHECK_ARG(nant <= 65535 * GF_AB && nvec <= 65535,
+                  "hydra_gain_basis_fwd: nant <= 65535 * 16, nvec <= 65535");
+  dim3 grid((nft + 255) / 256, (nant + GF_AB - 1) / GF_AB, nvec);
   gain_basis_fwd_kernel<<<grid, 256, 0, as_stream(stream)>>>(
       x, reinterpret_cast<const f64x2*>(Fbasis), pspec_sqrt, nant, nmodes, nft,
       reinterpret_cast<f64x2*>(g));
@@ -866,8 +909,8 @@ int hydra_gain_basis_adj(const double* y, int nvec, int nant, int nmodes, int nf
   HYDRA_CHECK_ARG(y && Fbasis && out && nvec > 0 && nant > 0 && nmodes > 0 && nft > 0,
                   "hydra_gain_basis_adj: bad arguments");
   HYDRA_CHECK_ARG(nvec <= 65535, "hydra_gain_basis_adj: nvec <= 65535");
-  dim3 grid(nant, nvec);
-  gain_basis_adj_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+  dim3 grid((nant + GA_AB - 1) / GA_AB, nvec);
+  gain_basis_adj_kernel<<<grid, 64 * GA_WAVES, 0, as_stream(stream)>>>(
       reinterpret_cast<const f64x2*>(y), reinterpret_cast<const f64x2*>(Fbasis), pspec_sqrt, add,
       nant, nmodes, nft, out);
   HYDRA_CHECK_LAUNCH("hydra_gain_basis_adj");
