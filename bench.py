@@ -64,8 +64,10 @@ SH_CONFIGS = {
     # per-pixel operator, left-hand-side matrix accumulated over LST blocks at set-up)
     "c3t40": ((7, 13), 40, 32, 128, 40),
     "c3st": ((4, 7), 10, 8, 8, 5),
+    # c3's size through the same factored path: no operator in memory although it would fit
+    "c3f": ((7, 13), 40, 32, 128, 4),
 }
-SH_STREAMED = ("c3t40", "c3st")
+SH_STREAMED = ("c3t40", "c3st", "c3f")
 GAIN_CONFIGS = {
     # linearised gain head -- name: (hex_spec, Nf, Nt, nmaxfreq, nmaxtime, batch)
     # c4 = BASELINE config 4 (HERA-331 per-antenna perturbations, batched CG matvecs)
@@ -299,7 +301,8 @@ def main_sh_streamed(args, comm, rank, world, dev):
         "higher_is_better": True, "scaling": "strong", "vs_baseline": None, "dtype": "f64",
         "data": "synthetic",
         "config": {
-            "workload": (f"BASELINE config 3 at SURVEY 8(d)'s size ({args.config}): SH diffuse GCR, "
+            "workload": (f"BASELINE config 3 ({args.config}"
+                         + (", SURVEY 8(d)'s 40 LSTs" if nt == 40 else "") + "): SH diffuse GCR, "
                          f"hex{hex_spec} = {nant} antennas / {nbl} baselines, lmax {lmax} ({nm} real "
                          f"modes), nside {nside}, {nf} freqs x {nt} times, complex128; the response "
                          f"operator ({16e-9 * m_all * nm:.0f} GB) is never formed: pixel voltages "
