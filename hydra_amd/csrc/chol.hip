@@ -543,6 +543,20 @@ using namespace hydra;
 // Small matrices: below this the 32-wide path (a chain of ~4 n / 32 short launches) wins.
 static constexpr int CHOL_BLOCKED_MIN_N = 6144;
 
+static int chol_small_solve(const double* A, double* b, int n, hipStream_t s) {
+  size_t b_bytes = (size_t)n * sizeof(double);
+  int use_lds = b_bytes <= 96 * 1024;   // b rides in LDS when it fits beside the staging tiles
+  if (use_lds) {
+    int rc = reserve_lds(reinterpret_cast<const void*>(trsv_fused_kernel<true>), b_bytes);
+    if (rc) return rc;
+    trsv_fused_kernel<true><<<1, TRSV_T, b_bytes, s>>>(A, n, n, b, 0, 2);   // L y = b, then L^T x = y
+  } else {
+    trsv_fused_kernel<false><<<1, TRSV_T, 0, s>>>(A, n, n, b, 0, 2);
+  }
+  HYDRA_CHECK_LAUNCH("hydra_chol_solve(solve)");
+  return HYDRA_OK;
+}
+
 static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_t s) {
   dim3 tb(NB, NB);
   potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, 0, info_dev);
@@ -556,17 +570,7 @@ static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_
     }
   }
   HYDRA_CHECK_LAUNCH("hydra_chol_solve(factor)");
-  size_t b_bytes = (size_t)n * sizeof(double);
-  int use_lds = b_bytes <= 96 * 1024;   // b rides in LDS when it fits beside the staging tiles
-  if (use_lds) {
-    int rc = reserve_lds(reinterpret_cast<const void*>(trsv_fused_kernel<true>), b_bytes);
-    if (rc) return rc;
-    trsv_fused_kernel<true><<<1, TRSV_T, b_bytes, s>>>(A, n, n, b, 0, 2);   // L y = b, then L^T x = y
-  } else {
-    trsv_fused_kernel<false><<<1, TRSV_T, 0, s>>>(A, n, n, b, 0, 2);
-  }
-  HYDRA_CHECK_LAUNCH("hydra_chol_solve(solve)");
-  return HYDRA_OK;
+  return b ? chol_small_solve(A, b, n, s) : HYDRA_OK;
 }
 
 // Columns are finished 256 at a time (32-wide steps capped at the sub-panel's last column), but the
@@ -644,15 +648,25 @@ static int chol_solve_blocked(const double* A, double* b, int n, hipStream_t s) 
   return HYDRA_OK;
 }
 
+static bool chol_takes_blocked(const double* A, const double* b, int n) {
+  return n >= CHOL_BLOCKED_MIN_N && n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+         reinterpret_cast<uintptr_t>(b) % 16 == 0;
+}
+
 extern "C" {
 
+int hydra_chol_apply(const double* L, double* b, int n, void* stream) {
+  HYDRA_CHECK_ARG(L && b && n > 0, "hydra_chol_apply: bad arguments");
+  hipStream_t s = as_stream(stream);
+  if (chol_takes_blocked(L, b, n)) return chol_solve_blocked(L, b, n, s);
+  return chol_small_solve(L, b, n, s);
+}
+
 int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream) {
-  HYDRA_CHECK_ARG(A && b && info_dev && n > 0, "hydra_chol_solve: bad arguments");
+  HYDRA_CHECK_ARG(A && info_dev && n > 0, "hydra_chol_solve: bad arguments");
   // (odd n: rows are not 16-byte aligned for the LDS-DMA of the blocked path -- callers pad, as
   // hydra_amd.linear_solver.solve_dense does)
-  if (n >= CHOL_BLOCKED_MIN_N && n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
-      reinterpret_cast<uintptr_t>(b) % 16 == 0)
-    return hydra_chol_solve_blocked(A, b, n, info_dev, stream);
+  if (chol_takes_blocked(A, b, n)) return hydra_chol_solve_blocked(A, b, n, info_dev, stream);
   hipStream_t s = as_stream(stream);
   hipError_t e = hipMemsetAsync(info_dev, 0, sizeof(int32_t), s);
   if (e != hipSuccess) return fail(HYDRA_ERR_HIP, "hydra_chol_solve: %s", hipGetErrorString(e));

@@ -201,6 +201,40 @@ def solve_dense(Amat, bvec, overwrite_a=False):
     return _dev.like(bvec, b)
 
 
+def cho_factor(Amat, overwrite_a=False):
+    """Cholesky factor of a symmetric positive-definite operator, kept on the GPU for
+    ``cho_solve`` (the names follow scipy.linalg).  For systems whose matrix does not change from
+    sample to sample -- the SH head's ``R^T N^-1 R + S^-1`` (sh_sampler.py:389-402) -- one
+    factorisation replaces the CG the reference runs per sample (example.py:1014-1052) by two
+    triangular solves; the result is the exact solution the CG converges to."""
+    A = _dev.f64(Amat)
+    n = A.shape[0]
+    assert tuple(A.shape) == (n, n)
+    if n >= BLOCKED_MIN_N and n % 2 == 1:
+        Ap = torch.zeros((n + 1, n + 1), dtype=torch.float64, device=A.device)
+        Ap[:n, :n] = A
+        Ap[n, n] = 1.0
+        A, overwrite_a = Ap, True
+    elif not (overwrite_a and A is Amat):
+        A = A.clone()
+    info = _dev.zeros((1,), torch.int32)
+    _dev.call("hydra_chol_solve", _dev.ptr(A), _dev.ptr(None), A.shape[0], _dev.ptr(info),
+              _dev.stream_ptr())
+    if int(info.item()) != 0:
+        raise np.linalg.LinAlgError("matrix is not positive definite")
+    return A, n
+
+
+def cho_solve(factor, bvec):
+    """x = A^-1 b from ``cho_factor``'s result."""
+    L, n = factor
+    np_ = L.shape[0]
+    b = torch.zeros(np_, dtype=torch.float64, device=L.device)
+    b[:n] = _dev.f64(bvec).reshape(-1)
+    _dev.call("hydra_chol_apply", _dev.ptr(L), _dev.ptr(b), np_, _dev.stream_ptr())
+    return _dev.like(bvec, b[:n] if np_ != n else b)
+
+
 # ------------------------------------------------------------------ row-sharded operator
 
 class RowShardedOperator:

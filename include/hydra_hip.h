@@ -369,8 +369,16 @@ int hydra_cg_solve_dense(const double* A, const double* b, double* x, int n, int
 
 /* Dense fallback: solve A x = b for symmetric positive definite A by blocked Cholesky
  * (stands for scipy.linalg.solve(A, b, assume_a='her'), example.py:944).  A is overwritten
- * by its factor; b by x.  Returns 1 if A is not positive definite.                       */
+ * by its factor (lower triangle); b by x; b == NULL: factor only.  *info_dev = 1 if A is not
+ * positive definite.                                                                      */
 int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream);
+
+/* b <- A^-1 b from the factor hydra_chol_solve left in A (the two triangular solves alone): for
+ * systems whose matrix stays the same from sample to sample -- the SH head's left-hand side
+ * R^T N^-1 R + S^-1 (sh_sampler.py:389-402) changes only with the noise and prior variances, so
+ * one factorisation serves every sample of a run where the reference runs CG anew each time
+ * (example.py:1014-1052).  Same alignment rules as hydra_chol_solve.                        */
+int hydra_chol_apply(const double* L, double* b, int n, void* stream);
 
 /* The large-matrix algorithm behind hydra_chol_solve (taken automatically for even n >= 6144):
  * 256-wide panels factored by 32-wide steps, then ONE rank-256 update of the rest of the lower

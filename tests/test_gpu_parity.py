@@ -388,6 +388,24 @@ def test_dense_fallback_matches_scipy(hy):
 
 # ------------------------------------------------------------------ gains helper
 
+@pytest.mark.parametrize("n", [1, 33, 257, 1681, 6145])
+def test_cho_factor_then_solves_match_scipy(hy, n):
+    """Factor once, solve many (the SH head's constant left-hand side): every right-hand side
+    against scipy's dense solve, and the factor-only call leaves what hydra_chol_apply reads
+    (6145: the matrix-core path from 6144 on, padded to even size)."""
+    import scipy.linalg
+    rng = np.random.RandomState(n)
+    M = rng.randn(n, n)
+    A = M @ M.T + n * np.eye(n)
+    fac = hy.linear_solver.cho_factor(A)
+    for k in range(3):
+        b = rng.randn(n)
+        x = hy.linear_solver.cho_solve(fac, b)
+        assert relerr(x, scipy.linalg.solve(A, b, assume_a="pos")) < 1e-11
+    with pytest.raises(np.linalg.LinAlgError):
+        hy.linear_solver.cho_factor(A - 2 * np.diag(np.diag(A)))
+
+
 def test_apply_gains_matches_reference_golden(hy):
     g = load_golden("gains.npz")
     ap = _pairs(g["antpairs"])
