@@ -319,7 +319,10 @@ def main_sh_streamed(args, comm, rank, world, dev):
             "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
         },
         "setup_voltages_s": t_volt, "setup_lhs_matrix_s": t_lhs,
-        "setup_lhs_tflops": (2.0 * m_loc * op.npix * nm + 2.0 * m_loc * nm * (nm + 1)) / t_lhs / 1e12,
+        "setup_lhs_path": ("closed form through pixel space (baseline-independent weights, complete array)"
+                           if op.fac.last_gram_kernel == "gram_uniform_kernel" else
+                           "Gram of the regenerated operator, LST block by LST block"),
+        "setup_lhs_tflops_operator_form": (2.0 * m_loc * op.npix * nm + 2.0 * m_loc * nm * (nm + 1)) / t_lhs / 1e12,
         "sample_rel_residual": resid,
         "roofline": ({
             "bound": "mfma", "achieved": flops / (adj_ms * 1e-3) / 1e12, "peak": 78.6,

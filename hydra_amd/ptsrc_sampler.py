@@ -82,10 +82,16 @@ class FactoredProj:
     def channel(self, j):
         """The operator of frequency channel ``j`` alone (a view of V, tables shared) -- for
         heads whose channels do not talk to each other (cosmo_sampler.py:276-284)."""
+        return self.channels(j, j + 1)
+
+    def channels(self, j0, j1):
+        """The operator of frequency channels [j0, j1) (a view of V, tables shared)."""
         sub = object.__new__(FactoredProj)
         sub.__dict__.update(self.__dict__)
-        sub.V = self.V[j:j + 1]
-        sub.shape = (self.shape[0], 1) + tuple(self.shape[2:])
+        sub.__dict__.pop("_plan_cache", None)
+        sub.__dict__.pop("_chan_plan_cache", None)
+        sub.V = self.V[j0:j1]
+        sub.shape = (self.shape[0], j1 - j0) + tuple(self.shape[2:])
         return sub
 
     @property

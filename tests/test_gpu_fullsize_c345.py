@@ -465,6 +465,18 @@ def test_streamed_sh_operator_matches_materialised_operator_and_oracle():
     A_ref = R_ref.real.T @ (w[:, None] * R_ref.real) + R_ref.imag.T @ (w[:, None] * R_ref.imag) \
         + np.diag(ip)
     assert relerr(A, A_ref) < 1e-10 and np.array_equal(A, A.T)
+    # weights that do not depend on the baseline: the closed form through pixel space, against
+    # the block-accumulated form and the oracle; in several frequency chunks too
+    wu = np.broadcast_to(300.0 + 200.0 * rng.rand(1, 4, 5), (op.nbl, 4, 5)).reshape(-1).copy()
+    A_ref = R_ref.real.T @ (wu[:, None] * R_ref.real) + R_ref.imag.T @ (wu[:, None] * R_ref.imag) \
+        + np.diag(ip)
+    assert op.fac._noise_plan(hy._dev.f64(wu).reshape(op.nbl, 4, 5))[0] == "uniform"
+    A_cf = op.lhs_matrix(wu, ip).cpu().numpy()
+    A_bl = op.lhs_matrix(wu, ip, closed_form=False).cpu().numpy()
+    assert relerr(A_cf, A_ref) < 1e-10 and relerr(A_bl, A_ref) < 1e-10
+    assert np.array_equal(A_cf, A_cf.T)
+    op.LHS_CHUNK_BYTES = 1          # one channel at a time
+    assert relerr(op.lhs_matrix(wu, ip).cpu().numpy(), A_ref) < 1e-10
     # and the materialised HIP operator agrees with both
     R, _, _ = sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside, latitude=LAT,
                                                   ref_freq=110.0, spectral_idx=-2.5, cross_only=True)
@@ -501,3 +513,11 @@ def test_c3_streamed_operator_full_array_equals_resident_operator(c3):
     A_res = sh_sampler.lhs_matrix(w, ip, R)
     A_str = op.lhs_matrix(w, ip)
     assert float((A_str - A_res).abs().max() / A_res.abs().max()) < 1e-11
+    # baseline-independent weights: the closed form through pixel space
+    nbl, nf, nt = op.nbl, op.nf, op.nt
+    wu = (300.0 + 200.0 * torch.rand((1, nf, nt), dtype=torch.float64, device=R.device,
+                                     generator=gen)).expand(nbl, nf, nt).contiguous().reshape(-1)
+    A_res = sh_sampler.lhs_matrix(wu, ip, R)
+    A_cf = op.lhs_matrix(wu, ip)
+    assert float((A_cf - A_res).abs().max() / A_res.abs().max()) < 1e-11
+    assert torch.equal(A_cf, A_cf.T)
