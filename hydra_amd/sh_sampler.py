@@ -322,18 +322,32 @@ class StreamedSHOperator:
         Re(P^H W P) has the closed form in the antenna voltages of csrc/gram.hip
         (``gram_uniform_kernel``: a rank-Nant update per (f,t) where the operator's Gram is a
         rank-Nbl one) -- 3.8 s -> 0.5 s at config 3, no block of the operator is ever formed.
-        Pixels below the horizon have zero voltage and contribute exact zeros."""
+        Only the pixels above the horizon at some LST of the run enter it."""
         nf, nt, nant, npix = self.V.shape
-        per_chan = nt * (nant + 1) * npix * 16
+        # pixels that are above the horizon at some LST of the run (the others have zero voltage
+        # at every (f,t): exact zeros in the Gram); the Gram's cost goes with their number squared
+        if getattr(self, "_visible", None) is None:
+            mask = torch.zeros(npix, dtype=torch.bool, device=self.V.device)
+            for j in range(nf):
+                mask |= (self.V[j] != 0).any(dim=0).any(dim=0)
+            self._visible = mask.nonzero().squeeze(1)
+        idx = self._visible if self._visible.numel() < 0.9 * npix else None
+        nv = npix if idx is None else int(idx.numel())
+        ymap = self.ymap if idx is None else self.ymap.index_select(0, idx)
+        per_chan = nt * (nant + 1) * nv * 16 * (1 if idx is None else 2)
         step = max(1, int(self.LHS_CHUNK_BYTES // per_chan))
         Gp = None
         for j0 in range(0, nf, step):
             j1 = min(nf, j0 + step)
-            G = self.fac.channels(j0, j1).gram(None, None,
-                                               plan=("uniform", w_ft[j0 * nt:j1 * nt].contiguous()))
+            sub = self.fac.channels(j0, j1)
+            if idx is not None:
+                sub.V = self.V[j0:j1].index_select(3, idx)
+                sub.shape = tuple(sub.shape[:3]) + (nv,)
+            G = sub.gram(None, None, plan=("uniform", w_ft[j0 * nt:j1 * nt].contiguous()))
             Gp = G if Gp is None else Gp.add_(G)
+            del sub
         self.fac.last_gram_kernel = "gram_uniform_kernel"
-        A = self.ymap_t @ (Gp @ self.ymap)
+        A = ymap.T @ (Gp @ ymap)
         # the product is symmetric up to rounding; the solvers read half of a matrix marked symmetric
         return torch.tril(A) + torch.tril(A, -1).T
 
