@@ -361,6 +361,44 @@ def case_shmpi(comm):
     comm.barrier()
 
 
+def case_shstream(comm):
+    """StreamedSHOperator with the frequency channels split over ranks (bench.py's c3t40 / c3f on
+    N GPUs): lhs_matrix(comm=) -- closed form through pixel space and block-accumulated -- and
+    construct_rhs(comm=) on every rank == the single-process operator over all channels; the
+    factor-once solve on the replicated matrix."""
+    import hydra_amd as hy
+    from hydra_amd import sh_sampler
+    rank, size = comm.Get_rank(), comm.Get_size()
+    ant_pos = hy.utils.build_hex_array(hex_spec=(2, 3), d=14.6)
+    freqs, lsts = np.linspace(100.0, 120.0, 4), np.linspace(0.2, 0.5, 3)
+    lmax, nside = 5, 8
+    beams = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    full = sh_sampler.StreamedSHOperator(freqs, lsts, beams, ant_pos, lmax, nside, time_block=2)
+    nbl, nf, nt, nm = full.nbl, full.nf, full.nt, full.nm
+    rng = np.random.RandomState(31)
+    ip = 50.0 + 50.0 * rng.rand(nm)
+    d = rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)
+    om1 = (rng.randn(nbl, nf, nt) + 1j * rng.randn(nbl, nf, nt)) / np.sqrt(2)
+    om0, a0 = rng.randn(nm), 0.1 * rng.randn(nm)
+    fidx = np.array_split(np.arange(nf), size)[rank]
+    mine = sh_sampler.StreamedSHOperator(freqs[fidx], lsts, beams, ant_pos, lmax, nside, time_block=2)
+    for uniform in (True, False):
+        w = (300.0 + 200.0 * rng.rand(1 if uniform else nbl, nf, nt)) * np.ones((nbl, 1, 1))
+        A1 = full.lhs_matrix(w.reshape(-1), ip).cpu().numpy()
+        b1 = full.construct_rhs(d.reshape(-1), w.reshape(-1), ip, om0, om1.reshape(-1), a0).cpu().numpy()
+        wk = np.ascontiguousarray(w[:, fidx]).reshape(-1)
+        A2 = mine.lhs_matrix(wk, ip, comm=comm)
+        assert (mine.fac.last_gram_kernel == "gram_uniform_kernel") == uniform
+        b2 = mine.construct_rhs(np.ascontiguousarray(d[:, fidx]).reshape(-1), wk, ip, om0,
+                                np.ascontiguousarray(om1[:, fidx]).reshape(-1), a0, comm=comm)
+        A2n, b2n = A2.cpu().numpy(), b2.cpu().numpy()
+        assert np.max(np.abs(A2n - A1)) <= 1e-11 * np.max(np.abs(A1)) and np.array_equal(A2n, A2n.T)
+        assert np.max(np.abs(b2n - b1)) <= 1e-11 * np.max(np.abs(b1))
+        x = hy.linear_solver.cho_solve(hy.linear_solver.cho_factor(A2), b2).cpu().numpy()
+        assert np.max(np.abs(x - np.linalg.solve(A1, b1))) <= 1e-9 * np.max(np.abs(x))
+    comm.barrier()
+
+
 def case_gainmpi(comm):
     """Gain head with the frequency channels split over ranks: construct_rhs_mpi and
     apply_operator_mpi (gain_sampler.py:145-301, Bcast + Allreduce per call) and the CG with one
@@ -588,7 +626,7 @@ if __name__ == "__main__":
         {"comm": case_comm, "blocks": case_blocks, "ptsrc": case_ptsrc,
          "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
          "rowshard": case_rowshard, "shmpi": case_shmpi, "gainmpi": case_gainmpi,
-         "symreduce": case_symreduce, "driver": case_driver, "nccl1": case_nccl1,
+         "symreduce": case_symreduce, "shstream": case_shstream, "driver": case_driver, "nccl1": case_nccl1,
          "cholrows": case_cholrows}[case](comm)
     except BaseException:
         import traceback

@@ -85,6 +85,11 @@ def test_sh_head_rows_split_over_ranks_world3():
 
 
 @pytest.mark.gpu
+def test_streamed_sh_operator_channels_split_over_ranks_world2():
+    _run("shstream", 2)
+
+
+@pytest.mark.gpu
 def test_gain_head_channels_split_over_ranks_world2():
     _run("gainmpi", 2)
 
