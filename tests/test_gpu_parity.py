@@ -388,6 +388,41 @@ def test_dense_fallback_matches_scipy(hy):
 
 # ------------------------------------------------------------------ gains helper
 
+def test_operator_cg_reads_the_flag_on_a_learned_schedule(hy):
+    """cg(linear_op=) enqueues iterations in blocks between reads of the device-side converged
+    flag; steps past convergence are no-ops but their operator applications are real work.  The
+    second solve of a system of the same size starts with a block of the first one's iteration
+    count: same iterates bit for bit, at most a couple of surplus applications."""
+    import torch
+    from hydra_amd import _dev, linear_solver
+    rng = np.random.RandomState(12)
+    n = 300
+    M = rng.randn(n, n)
+    A = _dev.f64(M @ M.T / n + np.diag(1.0 + rng.rand(n)))
+    b = _dev.f64(rng.randn(n))
+    calls = [0]
+
+    def op(v):
+        calls[0] += 1
+        return A @ v
+
+    linear_solver._ITER_HISTORY.clear()
+    x1, it1 = linear_solver.cg(None, b, linear_op=op, abs_tol=1e-10, return_iters=True)
+    c1 = calls[0]
+    calls[0] = 0
+    x2, it2 = linear_solver.cg(None, b, linear_op=op, abs_tol=1e-10, return_iters=True)
+    c2 = calls[0]
+    assert it1 == it2 and 0 < it1 < 1000 and torch.equal(x1, x2)
+    assert it1 <= c1 <= it1 + linear_solver.CHECK_EVERY       # blocks of CHECK_EVERY, no history
+    assert c2 == it2                                          # the learned first block is exact here
+    # a harder right-hand side of the same size: the first block falls short, short blocks follow
+    b3 = _dev.f64(rng.randn(n) * 1e3)
+    calls[0] = 0
+    x3, it3 = linear_solver.cg(None, b3, linear_op=op, abs_tol=1e-10, return_iters=True)
+    assert it3 >= it2 and it3 <= calls[0] <= it3 + max(2, it2 // 16)
+    assert relerr(x3.cpu().numpy(), np.linalg.solve(A.cpu().numpy(), b3.cpu().numpy())) < 1e-9
+
+
 @pytest.mark.parametrize("n", [1, 33, 257, 1681, 6145])
 def test_cho_factor_then_solves_match_scipy(hy, n):
     """Factor once, solve many (the SH head's constant left-hand side): every right-hand side

@@ -36,5 +36,29 @@ def pmc(db):
         print(f'"{short(n)}","{c}",{d},{v:.0f},{v / max(d, 1):.1f}')
 
 
+def timeline(db, first="gain_prepare_stream", nth=-1):
+    """Kernels from the nth launch of `first` to the next one, with the idle time before each:
+    where a step's wall time goes that the per-kernel sums do not show."""
+    con = sqlite3.connect(db)
+    rows = con.execute('select name, start, "end" from kernels order by start').fetchall()
+    marks = [i for i, r in enumerate(rows) if first in r[0]]
+    j = int(nth) % len(marks)
+    a = marks[j]
+    b = marks[j + 1] if j + 1 < len(marks) else len(rows)
+    t0, busy, idle, prev_end = rows[a][1], 0, 0, rows[a][1]
+    agg = {}
+    for n, st, en in rows[a:b]:
+        gap = max(0, st - prev_end)
+        k = short(n)
+        e = agg.setdefault(k, [0, 0, 0])
+        e[0] += 1; e[1] += en - st; e[2] += gap
+        busy += en - st; idle += gap; prev_end = max(prev_end, en)
+    print(f"step of {b - a} kernels: wall {1e-6 * (prev_end - t0):.3f} ms, busy {1e-6 * busy:.3f} ms, "
+          f"idle between kernels {1e-6 * idle:.3f} ms")
+    print('"Name","Calls","BusyUs","IdleBeforeUs"')
+    for k, (c, bu, gp) in sorted(agg.items(), key=lambda kv: -kv[1][1] - kv[1][2]):
+        print(f'"{k}",{c},{bu / 1e3:.1f},{gp / 1e3:.1f}')
+
+
 if __name__ == "__main__":
-    {"stats": stats, "pmc": pmc}[sys.argv[1]](sys.argv[2])
+    {"stats": stats, "pmc": pmc, "timeline": timeline}[sys.argv[1]](*sys.argv[2:])
