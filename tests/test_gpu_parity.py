@@ -433,10 +433,13 @@ def test_cho_factor_then_solves_match_scipy(hy, n):
     M = rng.randn(n, n)
     A = M @ M.T + n * np.eye(n)
     fac = hy.linear_solver.cho_factor(A)
+    assert (fac.linv is not None) == (n <= hy.linear_solver.INVERSE_FACTOR_MAX_N)
+    sub = hy.linear_solver.cho_factor(A, inverse_factor=False)      # the substitution path
     for k in range(3):
         b = rng.randn(n)
-        x = hy.linear_solver.cho_solve(fac, b)
-        assert relerr(x, scipy.linalg.solve(A, b, assume_a="pos")) < 1e-11
+        want = scipy.linalg.solve(A, b, assume_a="pos")
+        assert relerr(hy.linear_solver.cho_solve(fac, b), want) < 1e-11
+        assert relerr(hy.linear_solver.cho_solve(sub, b), want) < 1e-11
     with pytest.raises(np.linalg.LinAlgError):
         hy.linear_solver.cho_factor(A - 2 * np.diag(np.diag(A)))
 
