@@ -45,13 +45,17 @@ CONFIGS = {
     # 19 outriggers on a 300 m ring), gridded beam with bicubic interpolation,
     # baseline-sharded Gram + all-reduce; 8192 sources instead of 100 000, 8 channels x 1 time
     "c5s": ((11, 21), 8192, 8, 1),
-    # c5 = BASELINE config 5 at full source count on ONE GPU's share of the channels: 350 antennas,
-    # 100 000 sources (80 GB Gram), gridded beam; 2 channels x 1 time per step here (the node
-    # target is 128 channels over 8 GPUs = 16 per GPU); solved densely as the reference's driver
-    # does whatever --solver says (example.py:940-947): 256-wide-panel Cholesky on the matrix
-    # cores (csrc/chol.hip); --solver cg gives the reference's unpreconditioned CG instead
-    "c5": ((11, 21), 100000, 2, 1),
+    # c5 = BASELINE config 5: 350 antennas, 100 000 sources (80 GB Gram), gridded beam, 128
+    # channels x 1 time on 8 GPUs = 16 CHANNELS PER GPU: `--gpus N` runs 16 N channels (one GPU: its
+    # share of the node's job; 8 GPUs: the whole of config 5), so this config scales WEAKLY;
+    # solved densely as the reference's driver does whatever --solver says (example.py:940-947):
+    # 256-wide-panel Cholesky on the matrix cores (csrc/chol.hip), row-sharded over the ranks on
+    # more than one GPU; --solver cg gives the reference's unpreconditioned CG instead
+    "c5": ((11, 21), 100000, 16, 1),
+    # c5q = a quick look at the same system: 2 channels (what rounds 1-2 called c5)
+    "c5q": ((11, 21), 100000, 2, 1),
 }
+PER_GPU_CHANNELS = ("c5",)       # Nf above is per GPU: the job has Nf x n_gpus channels
 SH_CONFIGS = {
     # spherical-harmonic head -- name: (hex_spec, lmax, nside, Nf, Nt)
     # c3 = BASELINE config 3 (HERA-127, lmax 40, 128 freqs); Nt is left open by BASELINE.json and
@@ -607,6 +611,7 @@ def main_gain(args, comm, rank, world, dev):
                 t = op.local(v)
                 comm.allreduce_(t)
                 return v + t
+            lin.comm = comm
         x, iters = hy.linear_solver.cg(None, b, linear_op=lin, use_norm_tol=True,
                                        abs_tol=args.cg_tol, maxiters=1000, return_iters=True)
         return op, b, x, iters
@@ -832,7 +837,7 @@ def main_cosmo(args, comm, rank, world, dev):
             "rows_M": m_all, "solver": "cg", "cg_abs_tol": args.cg_tol, "cg_iters_last": int(iters),
             "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
         },
-        "gram_tflops_whole_job": world * base_flops / (gram_ms * 1e-3) / 1e12,
+        "gram_tflops_effective_baseline_form": world * base_flops / (gram_ms * 1e-3) / 1e12,
         "sample_rel_residual": resid,
         "roofline": {
             "bound": "mfma", "achieved": achieved, "peak": FP64_MATRIX_PEAK_TFLOPS,
@@ -1000,6 +1005,28 @@ def main_beam(args, comm, rank, world, dev):
     print(json.dumps(res))
 
 
+def self_launch(ngpus):
+    """``python bench.py --gpus N`` without torchrun's environment: run the same command line
+    under ``python -m torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1 at a free
+    port) as a CHILD process -- this process has made no GPU call and makes none -- and exit with
+    the child's status.  Rank 0's JSON line arrives on the inherited stdout."""
+    import socket
+    import subprocess
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, len(os.sched_getaffinity(0)) // ngpus)))
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1",
+           f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
+           os.path.abspath(__file__)] + sys.argv[1:]
+    sys.stdout.flush()
+    rc = subprocess.run(cmd, env=env).returncode
+    if rc != 0:
+        sys.exit(rc)
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -1022,6 +1049,8 @@ def main():
                          "as separate passes instead of gain_sampler.prepare_sample")
     ap.add_argument("--no-general", action="store_true",
                     help="skip the extra launches of the general Gram kernel after the timed region")
+    ap.add_argument("--no-fixed", action="store_true",
+                    help="ptsrc configs: skip the gains-fixed leg (operator and factor reused)")
     ap.add_argument("--shard", default=None, choices=["freq", "baseline"],
                     help="how the visibility rows are split over GPUs (default: freq; c5s: baseline)")
     ap.add_argument("--solver", default=None, choices=["dense", "cg", "cg-rows", "dense-rows"],
@@ -1032,6 +1061,12 @@ def main():
                          "layout factored in place by the row-sharded Cholesky "
                          "(linear_solver.solve_dense_rows; config 5 on > 1 GPU)")
     args = ap.parse_args()
+
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # started bare (`python bench.py --gpus N`): start the N ranks as a child torchrun, one
+        # process per GPU as in the reference's `mpirun -n N python example.py` (example.py:161-174),
+        # BEFORE anything here touches the GPU, and pass on its output and exit code
+        return self_launch(args.gpus)
 
     import torch
     import hydra_amd as hy
@@ -1056,13 +1091,16 @@ def main():
         return main_beam(args, comm, rank, world, dev)
 
     hex_spec, ns, nf, nt = CONFIGS[args.config]
-    big = args.config in ("c5s", "c5")
+    if args.config in PER_GPU_CHANNELS:
+        nf *= world
+    big = args.config in ("c5s", "c5", "c5q")
+    huge = args.config in ("c5", "c5q")
     shard = args.shard or ("baseline" if args.config == "c5s" else "freq")
     if args.solver is None:
         # one GPU factors the operator (config 5: 80 GB, 5.7 s); with more GPUs config 5 keeps the
         # summed Gram sharded by rows and the ranks factor it together
-        args.solver = "dense-rows" if (args.config == "c5" and world > 1) else "dense"
-    if args.config == "c5":
+        args.solver = "dense-rows" if (huge and world > 1) else "dense"
+    if huge:
         args.no_cpu = True     # the CPU path cannot form or solve a 100 000^2 system in minutes
     if args.solver == "cg-rows" and world == 1:
         args.solver = "cg"
@@ -1190,19 +1228,76 @@ def main():
     solve_ms = float(np.mean([s.elapsed_time(e) for s, e in solve_events])) if solve_events \
         else float("nan")
 
+    # ---- the same sample while the gains are NOT being sampled (ptsrc_sampler.SystemCache): the
+    # operator and its Cholesky factor depend on gains, noise weights and prior only, so a run
+    # that keeps the gains fixed (example.py without --gains) pays for them once and a sample is
+    # the right-hand side + two triangular sweeps.  Reported beside `value`, never as `value`:
+    # the reference rebuilds the operator in every iteration (example.py:878).
+    fixed = None
+    if args.solver in ("dense", "dense-rows") and not args.no_fixed:
+        if huge:
+            A = None                      # (consumed by the in-place factorisation anyway)
+        rows_mode = args.solver == "dense-rows"
+        cache = ptsrc_sampler.SystemCache()
+
+        def fixed_sample():
+            om_n = torch.randn((nbl, nf_loc, nt), dtype=torch.complex128, device=dev, generator=gen)
+            om_a = torch.randn(ns, dtype=torch.float64, device=dev, generator=gen)
+            _, b_c = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
+                                                  inv_noise, gains, prior, omega_n=om_n,
+                                                  omega_a=om_a, shard_rows=rows_mode, cache=cache)
+            if rows_mode or rank == 0:
+                x_c = cache.solve(b_c)
+            else:
+                x_c = torch.zeros(ns, dtype=torch.float64, device=dev)
+            if comm is not None and not rows_mode:
+                comm.bcast_(x_c, root=0)
+            return b_c, x_c
+
+        sync()
+        t0 = time.perf_counter()
+        fixed_sample()                    # builds the operator and factors it
+        sync()
+        t_first = time.perf_counter() - t0
+        fixed_sample()
+        nfix = max(args.steps, 5)
+        sync()
+        t0 = time.perf_counter()
+        for _ in range(nfix):
+            b_f, x_f = fixed_sample()
+        sync()
+        t_fix = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=dev)
+        if comm is not None:
+            comm.allreduce_(t_fix, op="max")
+        t_fix = float(t_fix.item())
+        assert cache.misses == 1 and cache.hits == nfix + 1, (cache.misses, cache.hits)
+        r_f = None
+        if rows_mode or rank == 0:
+            r_f = float((torch.linalg.norm(cache.matvec(x_f) - b_f) / torch.linalg.norm(b_f)).item())
+        fixed = {"value": nfix / t_fix, "unit": "samples/s", "ms_per_step": 1e3 * t_fix / nfix,
+                 "steps": nfix, "first_sample_s": t_first, "sample_rel_residual": r_f,
+                 "what": ("gains, noise weights and prior unchanged between samples: operator and "
+                          "Cholesky factor kept (ptsrc_sampler.SystemCache), per sample the "
+                          "right-hand side (R^H z) + two triangular sweeps; x is bit-identical to "
+                          "the rebuilding path (tests/test_gpu_parity.py)")}
+
     # sanity of the last sample (outside the timed region; the row-sharded product is collective).
-    # The in-place factorisation of the 80 GB operator consumed it: rebuild it from the same
-    # inputs (same Gram; b and x belong to the last sample's fluctuation draws, which only enter b)
-    if args.solver == "dense-rows":
-        if A is None:
-            A, _ = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
-                                                inv_noise, gains, prior, realisation=False,
-                                                shard_rows=True)
-        A = hy.linear_solver.RowShardedOperator(comm, A, ns)
-    elif A is None and rank == 0:
-        A, _ = ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs_loc, times, fac, data,
-                                            inv_noise, gains, prior, realisation=False)
-    Ax = A(x) if args.solver in ("cg-rows", "dense-rows") else (A @ x if rank == 0 else None)
+    # The in-place factorisation of the 80 GB operator consumed it: the cache of the gains-fixed leg
+    # holds the same operator (same inputs; b and x belong to the last sample's fluctuation
+    # draws, which only enter b), else rebuild it
+    if huge and fixed is not None:
+        Ax = cache.matvec(x) if (args.solver == "dense-rows" or rank == 0) else None
+    else:
+        if args.solver == "dense-rows":
+            if A is None:
+                A, _ = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
+                                                    inv_noise, gains, prior, realisation=False,
+                                                    shard_rows=True)
+            A = hy.linear_solver.RowShardedOperator(comm, A, ns)
+        elif A is None and rank == 0:
+            A, _ = ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs_loc, times, fac, data,
+                                                inv_noise, gains, prior, realisation=False)
+        Ax = A(x) if args.solver in ("cg-rows", "dense-rows") else (A @ x if rank == 0 else None)
     if rank != 0:
         return
     resid = float((torch.linalg.norm(Ax - b) / torch.linalg.norm(b)).item())
@@ -1280,13 +1375,19 @@ def main():
             "flagged_rows_corrected": int(getattr(fac, "last_gram_flagged_rows", 0)),
             "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU",
         },
-        # the metric's "Gram FP64 TFLOP/s": baseline-form flops 2 M Ns (Ns+1) over the Gram time,
-        # whole job (exceeds the matrix peak when the antenna-form kernel does the same Gram with
-        # fewer operations)
-        "gram_tflops_whole_job": world * effective,
+        # the metric's "Gram FP64 TFLOP/s" as an EFFECTIVE rate: baseline-form flops 2 M Ns (Ns+1)
+        # over the Gram time, whole job.  Not a roofline figure: it exceeds the matrix peak when
+        # the antenna-form kernel forms the same Gram with fewer operations (roofline* hold the
+        # executed-work rates)
+        "gram_tflops_effective_baseline_form": world * effective,
         "sample_rel_residual": resid,
         "roofline": roof_general if roof_general is not None else roof_ran,
     }
+    if fixed is not None:
+        out["gains_fixed"] = fixed
+    if args.config in PER_GPU_CHANNELS:
+        out["scaling"] = "weak"
+        out["config"]["channels_per_gpu"] = nf // world
     if roof_general is not None:
         out["roofline_closed_form"] = roof_ran
         out["general_vs_closed_form_relerr"] = agree

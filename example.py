@@ -259,9 +259,8 @@ def main(argv=None, on_head=None):
         t0 = time.time()
         # the left-hand side does not change between iterations: built once on the matrix cores
         # (the reference forms it inside every CG iteration, sh_sampler.py:393-398)
-        sh_lhs = hydra.sh_sampler.lhs_matrix(inv_noise_var_chunk, inv_prior_sh, sh_response,
-                                             comm=comm)
-        log("SH left-hand-side matrix took %6.3f sec" % (time.time() - t0), "c")
+        # (rebuilt below whenever the gains, which scale its noise weights, have changed)
+        sh_lhs = None
 
     # ---- Gibbs loop (example.py:663-1322)
     for n in range(args.Niters):
@@ -289,6 +288,7 @@ def main(argv=None, on_head=None):
                     t = op.local(v)
                     comm.allreduce_(t)
                     return v + t
+                lin.comm = comm           # cg: the ranks agree on when the converged flag is read
             xgain = hydra.linear_solver.cg(Amat=None, bvec=bgain, linear_op=lin, use_norm_tol=True)
             half = xgain.numel() // 2
             xg = torch.complex(xgain[:half], xgain[half:]).reshape(nants, ngm) * gain_pspec_sqrt_d
@@ -373,7 +373,14 @@ def main(argv=None, on_head=None):
             gg = hydra.apply_gains(torch.ones((nbl, nf, nt), dtype=torch.complex128, device=dev),
                                    g_now, ants, antpairs, inline=False)
             resid = data_chunk / gg - model_ptsrc
-            notify("sh", n, resid=resid, inv_noise_var=inv_noise_var_chunk,
+            # dividing the data by g_i g_j^* divides its noise variance by |g_i g_j|^2: both sides
+            # of the system use N^-1 |g_i g_j|^2
+            w_sh = inv_noise_var_chunk * (gg.real ** 2 + gg.imag ** 2)
+            if sh_lhs is None or args.sample_gains:
+                t1 = time.time()
+                sh_lhs = hydra.sh_sampler.lhs_matrix(w_sh, inv_prior_sh, sh_response, comm=comm)
+                log("SH left-hand-side matrix took %6.3f sec" % (time.time() - t1), "c")
+            notify("sh", n, resid=resid, inv_noise_var=w_sh,
                    inv_prior_var=inv_prior_sh, a_0=a_0, x0=sh_current, vis_response=sh_response)
             omega_a = np.random.randn(nmodes_sh)           # example.py:1022-1025
             omega_n = (1.0 * np.random.randn(nbl, nf, nt)
@@ -381,11 +388,11 @@ def main(argv=None, on_head=None):
             omega_n = tdev(omega_n, torch.complex128)
             if comm is None:
                 bsh = hydra.sh_sampler.construct_rhs_no_rot(
-                    resid.reshape(-1), inv_noise_var_chunk, inv_prior_sh,
+                    resid.reshape(-1), w_sh, inv_prior_sh,
                     tdev(omega_a, torch.float64), omega_n, a_0, sh_response)
             else:
                 bsh = hydra.sh_sampler.construct_rhs_no_rot_mpi(
-                    comm, resid.reshape(-1), inv_noise_var_chunk, inv_prior_sh, omega_a, omega_n,
+                    comm, resid.reshape(-1), w_sh, inv_prior_sh, omega_a, omega_n,
                     a_0, sh_response)
                 bsh = _dev.f64(bsh)
             if myid == 0:

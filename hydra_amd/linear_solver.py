@@ -21,28 +21,70 @@ from . import _dev
 
 CHECK_EVERY = 16
 
-#: iterations the last operator-form solve of a given size and tolerance needed.  The converged
-#: flag lives on the GPU and reading it stalls the queue, so iterations are enqueued in blocks
-#: and the steps enqueued past convergence are no-ops -- but their operator applications are not:
-#: with blocks of 16, config 4's gain solve (24 iterations, 0.41 ms each) ran 32 applications,
-#: 18 % of a sample.  Consecutive Gibbs samples need about the same number of iterations, so the
-#: first block is the last solve's count and the following ones are short.  The schedule only
-#: decides when the flag is read: the iterates and the result do not depend on it.
+#: iterations the last CONVERGED operator-form solve with a given operator, size and tolerance
+#: needed.  The converged flag lives on the GPU and reading it stalls the queue, so iterations
+#: are enqueued in blocks and the steps enqueued past convergence are no-ops -- but their operator
+#: applications are not: with blocks of 16, config 4's gain solve (24 iterations, 0.41 ms each)
+#: ran 32 applications, 18 % of a sample.  Consecutive Gibbs samples need about the same number
+#: of iterations, so the first block is the last solve's count and the following ones are short.
+#: The schedule only decides when the flag is read: the iterates and the result do not depend on
+#: it.  It does decide how many times the operator is CALLED, which matters when the operator
+#: holds a collective: the history is therefore kept per operator (``_history_key``), and an
+#: operator that names its communicator (``.comm``) has its prediction agreed across the ranks.
 _ITER_HISTORY = {}
 
+#: longest first block: a prediction is a number of operator applications enqueued blind
+FIRST_BLOCK_MAX = 8 * CHECK_EVERY
 
-def _block_sizes(key, as_torch):
+
+def _history_key(linear_op, explicit=None):
+    """What identifies an operator between solves: the caller's ``history_key``, the operator's
+    ``hydra_history_key`` attribute, or the code object behind the callable (a closure rebuilt
+    every Gibbs iteration at one call site keeps its key; two different call sites never share
+    one, so a root-only solve cannot change how often a collective operator is applied)."""
+    if explicit is not None:
+        return explicit
+    key = getattr(linear_op, "hydra_history_key", None)
+    if key is not None:
+        return key
+    fn = getattr(linear_op, "__func__", linear_op)            # bound method -> function
+    code = getattr(fn, "__code__", None)
+    if code is None:                                          # callable object
+        call = getattr(type(linear_op), "__call__", None)
+        code = getattr(call, "__code__", None)
+    return code
+
+
+def _predicted_iters(key, linear_op):
+    """The last converged solve's count for this key; agreed with the other ranks (the root's
+    value) when the operator names the communicator its collectives run on."""
+    pred = int(_ITER_HISTORY.get(key, 0)) if key[-1] is not None else 0
+    comm = getattr(linear_op, "comm", None)
+    if comm is not None and comm.Get_size() > 1:
+        t = torch.tensor([pred], dtype=torch.int64, device=_dev.device())
+        comm.bcast_(t, root=0)
+        pred = int(t.item())
+    return pred
+
+
+def _block_sizes(pred, as_torch):
     """Iterations to enqueue before each read of the converged flag."""
     if not as_torch:                 # a numpy operator synchronises every call anyway
         while True:
             yield 1
-    pred = _ITER_HISTORY.get(key, 0)
     if pred > 0:
-        yield pred
+        yield min(pred, FIRST_BLOCK_MAX)
         while True:
             yield max(2, pred // 16)
     while True:
         yield CHECK_EVERY
+
+
+def _record_iters(key, st, iters):
+    """Only a solve that set the converged flag is a prediction for the next one (a run into
+    ``maxiters`` would enqueue that many applications blind)."""
+    if key[-1] is not None and float(st[1].item()) != 0.0:
+        _ITER_HISTORY[key] = iters
 
 
 def mark_symmetric(A):
@@ -86,7 +128,7 @@ def _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0):
     return x, iters.value
 
 
-def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
+def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, history_key=None):
     """CG with a caller-supplied operator.  The operator is called with the same kind of array
     as ``bvec`` (numpy or GPU tensor) and may return either."""
     as_torch = _dev.is_torch(bvec)
@@ -108,8 +150,8 @@ def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
     _dev.call("hydra_cg_init", n, _dev.ptr(b), _dev.ptr(ax0), _dev.ptr(r), _dev.ptr(p),
               _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
     it = 0
-    key = (n, float(abs_tol), bool(use_norm_tol))
-    blocks = _block_sizes(key, as_torch)
+    key = (n, float(abs_tol), bool(use_norm_tol), _history_key(linear_op, history_key))
+    blocks = _block_sizes(_predicted_iters(key, linear_op), as_torch)
     while True:
         if float(st[1].item()) != 0.0 or it >= maxiters:
             break
@@ -119,11 +161,12 @@ def _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op):
                       _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
             it += 1
     iters = int(st[2].item())
-    _ITER_HISTORY[key] = iters
+    _record_iters(key, st, iters)
     return x, iters
 
 
-def _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, comm):
+def _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, comm,
+                       history_key=None):
     """The reference's ``cg(..., linear_op=, comm=)`` (linear_solver.py:441-499): ``linear_op``
     is COLLECTIVE (every rank must call it the same number of times; it synchronises its own
     input) and only the root's return value is valid -- e.g. ``apply_lhs_no_rot_mpi``, which
@@ -151,8 +194,15 @@ def _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, com
               _dev.ptr(st), float(abs_tol), int(bool(use_norm_tol)), sp)
     comm.bcast_(ps, root=0)
     it = 0
-    key = (n, float(abs_tol), bool(use_norm_tol), "root")    # the same history on every rank
-    blocks = _block_sizes(key, as_torch)
+    # every rank sees the root's flag and iteration count, but a rank may have recorded other
+    # solves under the same key: the root's prediction is the one all of them use
+    key = (n, float(abs_tol), bool(use_norm_tol), ("root", _history_key(linear_op, history_key)))
+    pred = int(_ITER_HISTORY.get(key, 0))
+    if comm.Get_size() > 1:
+        t = torch.tensor([pred], dtype=torch.int64, device=b.device)
+        comm.bcast_(t, root=0)
+        pred = int(t.item())
+    blocks = _block_sizes(pred, as_torch)
     while True:
         if float(st[1].item()) != 0.0 or it >= maxiters:      # the root's flag, on every rank
             break
@@ -163,12 +213,12 @@ def _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, com
             comm.bcast_(ps, root=0)
             it += 1
     iters = int(st[2].item())
-    _ITER_HISTORY[key] = iters
+    _record_iters(key, st, iters)
     return x, iters
 
 
 def cg(Amat, bvec, maxiters=1000, abs_tol=1e-8, use_norm_tol=False, x0=None, linear_op=None,
-       comm=None, return_iters=False):
+       comm=None, return_iters=False, history_key=None):
     """Conjugate-gradient solve of ``Amat x = bvec`` (linear_solver.py:378-509).
 
     ``linear_op`` (callable) replaces ``Amat`` when given.  With ``comm`` the solve is driven by
@@ -177,15 +227,20 @@ def cg(Amat, bvec, maxiters=1000, abs_tol=1e-8, use_norm_tol=False, x0=None, lin
     operator that already returns the summed result on EVERY rank (an all-reduce inside, e.g.
     ``RowShardedOperator`` or ``sh_sampler.LhsOperator``) needs no ``comm`` here: every rank then
     runs the same iteration on identical data, one collective per iteration instead of three.
+    Such an operator should carry its communicator as ``.comm`` (both of the above do): the
+    number of iterations enqueued between reads of the converged flag is learned from the last
+    solve with the same operator (``history_key``, default: the operator's code), and with
+    ``.comm`` the ranks agree on it, so that every rank applies the operator equally often.
     """
     if x0 is not None:
         assert tuple(x0.shape) == tuple(bvec.shape), (
             "Initial guess x0 has a different shape to bvec")
         assert x0.dtype == bvec.dtype, "Initial guess x0 has a different type to bvec"
     if linear_op is not None and comm is not None:
-        x, iters = _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, comm)
+        x, iters = _op_cg_root_driven(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, comm,
+                                      history_key)
     elif linear_op is not None:
-        x, iters = _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op)
+        x, iters = _op_cg(bvec, maxiters, abs_tol, use_norm_tol, x0, linear_op, history_key)
     elif comm is None or comm.Get_rank() == 0:
         x, iters = _dense_cg(Amat, bvec, maxiters, abs_tol, use_norm_tol, x0)
     else:       # only the root's matrix counts (:441-443); its solution arrives below
@@ -333,12 +388,63 @@ class RowShardedOperator:
 SUPER_PANEL = 2048
 
 
+class RowShardedFactor:
+    """Cholesky factor of an operator sharded by rows over the ranks of ``comm`` (what
+    ``factor_dense_rows`` returns): rank k holds rows ``comm.row_range(n, k)`` of L in the lower
+    triangle of ``A``.  ``solve(b)`` runs the two triangular sweeps, block row by block row."""
+
+    def __init__(self, comm, A, n):
+        self.comm, self.A, self.n = comm, A, n
+
+    def solve(self, bvec):
+        comm, A, n = self.comm, self.A, self.n
+        size, rank = comm.Get_size(), comm.Get_rank()
+        dev = A.device
+        b = _dev.f64(bvec)
+        assert b.numel() == n
+        # L y = b, block row by block row
+        y = b.clone()
+        for s in range(size):
+            s0, s1 = comm.row_range(n, s)
+            if s1 <= s0:
+                continue
+            if rank == s:
+                rhs = y[s0:s1] - (A[:, :s0] @ y[:s0] if s0 > 0 else 0.0)
+                y[s0:s1] = torch.linalg.solve_triangular(A[:, s0:s1], rhs[:, None], upper=False)[:, 0]
+            comm.bcast_(y[s0:s1], root=s)
+        # L^T x = y, from the last block up
+        x = y
+        for s in range(size - 1, -1, -1):
+            s0, s1 = comm.row_range(n, s)
+            if s1 <= s0:
+                continue
+            c = torch.zeros(max(s0, 1), dtype=torch.float64, device=dev)
+            if rank == s:
+                xs = torch.linalg.solve_triangular(A[:, s0:s1].T, x[s0:s1][:, None], upper=True)[:, 0]
+                x[s0:s1] = xs
+                if s0 > 0:
+                    c[:s0] = A[:, :s0].T @ xs
+            comm.bcast_(x[s0:s1], root=s)
+            if s0 > 0:
+                comm.bcast_(c, root=s)
+                x[:s0] -= c[:s0]
+        return _dev.like(bvec, x)
+
+
 def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
-    """The dense solve of the driver (``scipy.linalg.solve(A, b, assume_a='her')``,
+    """``factor_dense_rows(comm, A_rows).solve(bvec)``: the dense solve of the driver
+    (example.py:940-947) for an operator sharded by rows; x (n,) on every rank."""
+    n = int(_dev.f64(bvec).numel())
+    return factor_dense_rows(comm, A_rows, overwrite_a=overwrite_a, n=n).solve(bvec)
+
+
+def factor_dense_rows(comm, A_rows, overwrite_a=False, n=None):
+    """The factorisation half of the dense solve of the driver (``scipy.linalg.solve(A, b, assume_a='her')``,
     example.py:940-947) for an operator sharded by rows over the ranks of ``comm`` -- the layout
     ``precompute_mpi(..., shard_rows=True)`` leaves it in: rank k holds rows
-    ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n), ``bvec`` (n,) is the same on every rank.
-    Returns x (n,) on every rank.
+    ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n).  Returns a ``RowShardedFactor`` whose
+    ``solve(b)`` (b (n,), the same on every rank) gives x (n,) on every rank; a caller whose
+    operator does not change between samples factors once and solves per sample.
 
     Right-looking Cholesky, every rank working on its own rows.  Columns are finished 256 at a
     time: the 256 x 256 diagonal block is summed to all ranks (each owns some of its rows) and
@@ -353,8 +459,7 @@ def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
     A = _dev.f64(A_rows)
     if not (overwrite_a and A is A_rows):
         A = A.clone()
-    b = _dev.f64(bvec)
-    n = b.numel()
+    n = int(A.shape[1]) if n is None else int(n)
     size, rank = comm.Get_size(), comm.Get_rank()
     r0, r1 = comm.row_range(n)
     nloc = r1 - r0
@@ -401,7 +506,11 @@ def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
             bad |= info
             L = torch.tril(D)
             if d1 > d0:
-                A[d0 - r0:d1 - r0, k:kend] = L[d0 - k:d1 - k]
+                # the factor goes below the diagonal only: what is above it stays the operator
+                # (ptsrc_sampler.SystemCache.matvec reads it after the factorisation)
+                blk = A[d0 - r0:d1 - r0, k:kend]
+                low = torch.ones((pb, pb), dtype=torch.bool, device=dev).tril()[d0 - k:d1 - k]
+                blk.copy_(torch.where(low, L[d0 - k:d1 - k], blk))
             # this rank's rows of the panel below the block: X L^T = P
             i0 = max(r0, kend)
             rest = n - kend
@@ -425,33 +534,7 @@ def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
     comm.allreduce_(bad, op="max")
     if int(bad.item()) != 0:
         raise np.linalg.LinAlgError("matrix is not positive definite")
-    # L y = b, block row by block row
-    y = b.clone()
-    for s in range(size):
-        s0, s1 = comm.row_range(n, s)
-        if s1 <= s0:
-            continue
-        if rank == s:
-            rhs = y[s0:s1] - (A[:, :s0] @ y[:s0] if s0 > 0 else 0.0)
-            y[s0:s1] = torch.linalg.solve_triangular(A[:, s0:s1], rhs[:, None], upper=False)[:, 0]
-        comm.bcast_(y[s0:s1], root=s)
-    # L^T x = y, from the last block up
-    x = y
-    for s in range(size - 1, -1, -1):
-        s0, s1 = comm.row_range(n, s)
-        if s1 <= s0:
-            continue
-        c = torch.zeros(max(s0, 1), dtype=torch.float64, device=dev)
-        if rank == s:
-            xs = torch.linalg.solve_triangular(A[:, s0:s1].T, x[s0:s1][:, None], upper=True)[:, 0]
-            x[s0:s1] = xs
-            if s0 > 0:
-                c[:s0] = A[:, :s0].T @ xs
-        comm.bcast_(x[s0:s1], root=s)
-        if s0 > 0:
-            comm.bcast_(c, root=s)
-            x[:s0] -= c[:s0]
-    return _dev.like(bvec, x)
+    return RowShardedFactor(comm, A, n)
 
 
 # ------------------------------------------------------------------ 2-D block CG over ranks

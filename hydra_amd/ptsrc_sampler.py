@@ -262,6 +262,103 @@ class FactoredProj:
         return G
 
 
+class SystemCache:
+    """The point-source GCR operator kept between Gibbs samples.
+
+    ``A = 1 + S^1/2 Re(R^H N^-1 R) S^1/2`` and the model ``g_i g_j^* (R 1)`` depend on the gains,
+    the noise weights and the prior (ptsrc_sampler.py:48-106) -- not on the data or the
+    fluctuation draws -- yet the reference's driver rebuilds them in every iteration
+    (example.py:878).  Pass one ``SystemCache`` as ``precompute_mpi(..., cache=)``: while gains,
+    ``inv_noise_var`` and ``amp_prior_std`` hold the values of the last call (compared by
+    content on the GPU: the driver forms a new gain tensor every iteration, example.py:868-889),
+    a sample costs the right-hand side alone, and ``cache.solve(b)`` keeps the Cholesky factor as
+    well, so the dense solve of example.py:944 becomes two triangular sweeps.  Both return bit
+    for bit what the rebuilding path returns (``tests/test_gpu_parity.py``).
+
+    After the first ``solve`` the LOWER triangle of ``A`` holds the factor ``L`` (in place: the
+    100 000-source operator is 80 GB); the strict upper triangle and ``diag`` still hold the
+    operator, and ``matvec`` multiplies by it in either state."""
+
+    def __init__(self):
+        self.hits = self.misses = 0
+        self.clear()
+
+    def clear(self):
+        self.key = None
+        self.A = self.diag = self.gg = self.model = None
+        self.factor = None
+        self.rows = False            # A is this rank's row block (precompute_mpi(shard_rows=True))
+        self.comm = None
+
+    def _match(self, comm, proj, gains, w, sigma, shard_rows):
+        k = self.key
+        hit = (k is not None and k[0] is proj and k[4] == bool(shard_rows)
+               and k[5] == getattr(proj, "_version", None)
+               and k[1].shape == gains.shape and k[2].shape == w.shape
+               and k[3].shape == sigma.shape
+               and torch.equal(k[1], gains) and torch.equal(k[2], w) and torch.equal(k[3], sigma))
+        if comm is not None:         # every rank takes the same branch: its collectives differ
+            hit = comm.allreduce(1.0 if hit else 0.0, op="min") == 1.0
+        if hit:
+            self.hits += 1
+        else:
+            self.misses += 1
+            self.clear()             # frees the old operator before the new one is built
+        return hit
+
+    def _store(self, comm, proj, gains, w, sigma, shard_rows, A, gg, model, keep_A):
+        self.key = (proj, gains.clone(), w.clone(), sigma.clone(), bool(shard_rows),
+                    getattr(proj, "_version", None))
+        self.A = A if keep_A else None
+        self.gg, self.model = gg, model
+        self.rows, self.comm = bool(shard_rows), comm
+        self.factor = self.diag = None
+
+    @property
+    def factored(self):
+        return self.factor is not None
+
+    def solve(self, bvec):
+        """x = A^-1 b: ``linear_solver.solve_dense(A, b)`` (``solve_dense_rows`` for an operator
+        sharded by rows) with the factorisation done on the first call after a rebuild only."""
+        from . import linear_solver
+        assert self.A is not None, "SystemCache.solve: no operator (call precompute_mpi(cache=) first)"
+        if self.factor is None:
+            if self.rows:
+                r0, r1 = self.comm.row_range(self.A.shape[1])
+                self.diag = self.A.diagonal(offset=r0).clone()
+                self.factor = linear_solver.factor_dense_rows(self.comm, self.A, overwrite_a=True)
+            else:
+                self.diag = self.A.diagonal().clone()
+                self.factor = linear_solver.cho_factor(self.A, overwrite_a=True,
+                                                       inverse_factor=False)
+                self.A.hydra_symmetric = False      # its lower triangle is L from here on
+        if self.rows:
+            return self.factor.solve(bvec)
+        return linear_solver.cho_solve(self.factor, bvec)
+
+    def matvec(self, x, block=4096):
+        """A x, whether or not ``solve`` has overwritten the lower triangle with the factor (then
+        from the strict upper triangle, its transpose and the saved diagonal, in row blocks)."""
+        xd = _dev.f64(x)
+        n = self.A.shape[1]
+        r0, r1 = self.comm.row_range(n) if self.rows else (0, n)
+        if self.factor is None or (not self.rows and self.factor.L is not self.A):
+            y = torch.zeros(n, dtype=torch.float64, device=xd.device)
+            y[r0:r1] = self.A @ xd
+        else:
+            y = torch.zeros(n, dtype=torch.float64, device=xd.device)
+            y[r0:r1] = self.diag * xd[r0:r1]
+            for i0 in range(r0, r1, block):
+                i1 = min(i0 + block, r1)
+                U = torch.triu(self.A[i0 - r0:i1 - r0], diagonal=i0 + 1)
+                y[i0:i1] += U @ xd
+                y += U.T @ xd[i0:i1]
+        if self.rows:
+            self.comm.allreduce_(y)
+        return y
+
+
 def calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, beams,
                        latitude=-0.5361913261514378, materialize=True):
     """Visibility vector of each point source per (baseline, frequency, time): the projection
@@ -298,7 +395,7 @@ def _draw_omega_n(shape, realisation):
 
 def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, data_chunk,
                    inv_noise_var_chunk, gain_chunk, amp_prior_std, realisation=True,
-                   omega_n=None, omega_a=None, shard_rows=False):
+                   omega_n=None, omega_a=None, shard_rows=False, cache=None):
     """Linear operator and right-hand side of the point-source GCR system
     (ptsrc_sampler.py:17-140).  With ``comm`` (``hydra_amd._dist.Comm``) every rank passes its
     (freq, time) chunk and the partial Gram / RHS are summed over ranks; only the root's
@@ -308,7 +405,11 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
     every rank returns its rows ``comm.row_range(Ns)`` of ``A`` (a view of its partial Gram,
     reduced in place) and the full ``b``; solve with
     ``linear_solver.cg(None, b, linear_op=linear_solver.RowShardedOperator(comm, A_rows, Ns))``.
-    For source counts whose matrix one GPU holds but should not multiply alone (config 5)."""
+    For source counts whose matrix one GPU holds but should not multiply alone (config 5).
+
+    ``cache`` (a ``SystemCache``): keep the operator between calls and rebuild it only when the
+    gains, the noise weights or the prior have changed; the returned ``A`` is then the cache's
+    (do not modify it; after ``cache.solve`` its lower triangle holds the Cholesky factor)."""
     myid = comm.Get_rank() if comm is not None else 0
     bl_i_h, bl_j_h = _tables.baseline_indices(ants, antpairs)
     nbl = len(antpairs)
@@ -337,9 +438,15 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
     om_n = _dev.c128(omega_n)
     assert tuple(om_n.shape) == (nbl, nf, nt)
 
-    gg = _dev.empty((nbl, nf, nt), torch.complex128)
+    hit = cache is not None and cache._match(comm, proj_chunk, gains, w, sigma, shard_rows)
     prior_here = None if comm is not None else sigma
-    if factored:
+    A = None
+    if hit:
+        gg, model = cache.gg, cache.model
+        if not factored:
+            R = _dev.c128(proj_chunk).reshape(m, ns)
+    elif factored:
+        gg = _dev.empty((nbl, nf, nt), torch.complex128)
         if not (np.array_equal(bl_i_h, proj_chunk.bl_i_host)
                 and np.array_equal(bl_j_h, proj_chunk.bl_j_host)):
             raise ValueError("antpairs do not match the baselines of the factored operator")
@@ -348,6 +455,7 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         A = _timed_gram(lambda: proj_chunk.gram(gains, w, prior_std=prior_here))
         model = proj_chunk.apply(None, rowmul=gg)        # R 1, ptsrc_sampler.py:104-106
     else:
+        gg = _dev.empty((nbl, nf, nt), torch.complex128)
         R = _dev.c128(proj_chunk).reshape(m, ns)
         rows = _dev.empty((nbl, nf, nt), torch.complex128)
         _dev.call("hydra_row_factors", _dev.ptr(gains), _dev.ptr(w), _dev.ptr(bl_i),
@@ -361,6 +469,7 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         ones = torch.ones(ns, dtype=torch.float64, device=data.device)
         _dev.call("hydra_apply_R", _dev.ptr(R), m, ns, _dev.ptr(ones), _dev.ptr(gg),
                   _dev.ptr(model), st)
+        del ws, rows
 
     # z = conj(gg) ((d - model) N^-1 + omega_n N^-1/2)          ptsrc_sampler.py:104-123
     z = _dev.empty((nbl, nf, nt), torch.complex128)
@@ -385,26 +494,38 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
     if comm is not None and shard_rows:
         # block row k of the sum goes to rank k; prior and identity on the rank's rows
         # (ptsrc_sampler.py:91-94); omega_a is the root's draw on every rank
-        A = comm.reduce_rows_(A)
         comm.allreduce_(b)
-        r0, r1 = comm.row_range(ns)
-        if r1 > r0:
-            A.mul_(sigma[None, :]).mul_(sigma[r0:r1, None])
-            A.diagonal(offset=r0).add_(1.0)
+        if not hit:
+            A = comm.reduce_rows_(A)
+            r0, r1 = comm.row_range(ns)
+            if r1 > r0:
+                A.mul_(sigma[None, :]).mul_(sigma[r0:r1, None])
+                A.diagonal(offset=r0).add_(1.0)
         oa = om_a if myid == 0 else torch.zeros(ns, dtype=torch.float64, device=b.device)
         comm.bcast_(oa, root=0)
         b += oa
     elif comm is not None:
         # sum over ranks (comm.Reduce at ptsrc_sampler.py:86,132), then prior + omega_a on root
-        comm.reduce_sym_(A, root=0)      # lower triangle on the wire, mirrored on arrival
+        if not hit:
+            comm.reduce_sym_(A, root=0)      # lower triangle on the wire, mirrored on arrival
         comm.reduce_(b, root=0)
         if myid == 0:
-            _dev.call("hydra_prior_epilogue", _dev.ptr(A), ns, _dev.ptr(sigma), _dev.ptr(None), st)
+            if not hit:
+                _dev.call("hydra_prior_epilogue", _dev.ptr(A), ns, _dev.ptr(sigma), _dev.ptr(None),
+                          st)
             b += om_a
         else:
-            A = torch.zeros((1, 1), dtype=torch.float64, device=A.device)
+            A = torch.zeros((1, 1), dtype=torch.float64, device=b.device)
             b = torch.zeros((1,), dtype=torch.float64, device=b.device)
-    if _dev.is_torch(ref) and not shard_rows and A.shape[0] == A.shape[1]:
+    if cache is not None:
+        if hit:
+            if cache.A is not None:
+                A = cache.A
+        else:
+            keep_A = shard_rows or myid == 0
+            cache._store(comm, proj_chunk, gains, w, sigma, shard_rows, A, gg, model, keep_A)
+    if (_dev.is_torch(ref) and not shard_rows and A.shape[0] == A.shape[1]
+            and not (cache is not None and cache.factored)):
         A.hydra_symmetric = True      # mirrored exactly by the Gram finish / unpack kernels
     return _dev.like(ref, A), _dev.like(ref, b)
 

@@ -260,6 +260,30 @@ def case_rowshard(comm):
     x_ref = np.linalg.solve(A1, b1)
     assert 0 < iters < 500
     assert np.max(np.abs(x.cpu().numpy() - x_ref)) / np.max(np.abs(x_ref)) < 1e-8
+    # SystemCache over the ranks, rows sharded and rooted: one build, then reuse; every sample
+    # equal to the single-process system's solution with the same fluctuation vectors
+    for rows_mode in (True, False):
+        cache = hy.ptsrc_sampler.SystemCache()
+        for k in range(3):
+            rng = np.random.RandomState(50 + k)
+            om_n = (rng.randn(*p["om_n"].shape) + 1j * rng.randn(*p["om_n"].shape)) / np.sqrt(2)
+            om_a = rng.randn(ns)
+            _, bk = hy.ptsrc_sampler.precompute_mpi(
+                None, p["ants"], p["antpairs"], p["freqs"], p["times"], full, p["data"],
+                p["inv_noise"], p["gains"], p["prior"], omega_n=om_n, omega_a=om_a)
+            _, bc = hy.ptsrc_sampler.precompute_mpi(
+                comm, p["ants"], p["antpairs"], p["freqs"][fidx], p["times"], mine,
+                torch.as_tensor(p["data"][:, fidx], device=dev), p["inv_noise"][:, fidx],
+                p["gains"][:, fidx], p["prior"], omega_n=om_n[:, fidx],
+                omega_a=om_a if rank == 0 else None, shard_rows=rows_mode, cache=cache)
+            xk = np.linalg.solve(A1, bk)
+            if rows_mode or rank == 0:
+                xc = cache.solve(bc)
+                assert np.max(np.abs(xc.cpu().numpy() - xk)) / np.max(np.abs(xk)) < 1e-10, (rows_mode, k)
+                if rows_mode:
+                    yk = cache.matvec(xc).cpu().numpy()
+                    assert np.max(np.abs(yk - bk)) / np.max(np.abs(bk)) < 1e-10
+        assert (cache.misses, cache.hits) == (1, 2), (cache.misses, cache.hits)
     comm.barrier()
 
 
@@ -565,6 +589,64 @@ def case_cholrows(comm):
     comm.barrier()
 
 
+def case_cghist(comm):
+    """cg(linear_op=) with a collective operator when the ranks' iteration histories differ
+    (ADVICE round 2): rank 0 first solves, alone, an easier system of the same size and tolerance
+    through the SAME operator code; the collective solve that follows must still apply the
+    operator equally often on every rank (a surplus all-reduce on one rank would hang) and give
+    the single-process answer."""
+    from hydra_amd import linear_solver
+    rank, size = comm.Get_rank(), comm.Get_size()
+    dev = torch.device("cuda")
+    rng = np.random.RandomState(5)
+    n = 96
+    M = rng.randn(4 * n, n)
+    A = M.T @ M / n + np.eye(n)
+    b = rng.randn(n)
+    rows = np.array_split(np.arange(4 * n), size)[rank]
+    Mk = torch.as_tensor(M[rows], device=dev)
+    calls = [0]
+
+    class Op:
+        """(M^T M / n + 1) v with the rows of M split over the ranks: one all-reduce per call."""
+        def __init__(self, comm, scale):
+            self.comm, self.scale = comm, scale
+
+        def __call__(self, v):
+            calls[0] += 1
+            t = Mk.T @ (Mk @ v) / n * self.scale
+            if self.comm is not None:
+                self.comm.allreduce_(t)
+            return t + v
+
+    linear_solver._ITER_HISTORY.clear()
+    bd = torch.as_tensor(b, device=dev)
+    if rank == 0:      # a local solve, same operator code / size / tolerance, far fewer iterations
+        x_loc, it_loc = linear_solver.cg(None, bd, linear_op=Op(None, 1e-3), abs_tol=1e-10,
+                                         return_iters=True)
+        assert 0 < it_loc < 10
+    comm.barrier()
+    for _ in range(2):     # the second solve runs on the learned schedule
+        calls[0] = 0
+        x, iters = linear_solver.cg(None, bd, linear_op=Op(comm, 1.0), abs_tol=1e-10,
+                                    return_iters=True)
+        c = torch.tensor([float(calls[0])])
+        lo, hi = c.clone(), c.clone()
+        comm.allreduce_(lo, op="min")
+        comm.allreduce_(hi, op="max")
+        assert lo.item() == hi.item() == calls[0], (lo.item(), hi.item(), calls[0])
+        assert np.abs(x.cpu().numpy() - np.linalg.solve(A, b)).max() < 1e-8
+    assert iters <= calls[0] <= iters + max(2, iters // 16)
+    # the root-driven form (comm=): histories differ the same way, the root's prediction is used
+    if rank == 0:
+        linear_solver.cg(None, bd, linear_op=lambda v: v, comm=None, abs_tol=1e-10)
+    Ad = torch.as_tensor(A, device=dev)
+    for _ in range(2):
+        xr = linear_solver.cg(None, bd, linear_op=lambda v: Ad @ v, comm=comm, abs_tol=1e-10)
+        assert np.abs(xr.cpu().numpy() - np.linalg.solve(A, b)).max() < 1e-8
+    comm.barrier()
+
+
 def case_nccl1(comm):
     """Every collective of _dist.Comm on RCCL itself, with the one rank a 1-GPU box can hold:
     the nccl-only branches (GPU-resident numpy staging, reduce_scatter_tensor,
@@ -627,7 +709,7 @@ if __name__ == "__main__":
          "blshard": case_blshard, "cgmpi": case_cgmpi, "cosmo": case_cosmo,
          "rowshard": case_rowshard, "shmpi": case_shmpi, "gainmpi": case_gainmpi,
          "symreduce": case_symreduce, "shstream": case_shstream, "driver": case_driver, "nccl1": case_nccl1,
-         "cholrows": case_cholrows}[case](comm)
+         "cholrows": case_cholrows, "cghist": case_cghist}[case](comm)
     except BaseException:
         import traceback
         if logdir:

@@ -116,6 +116,11 @@ def test_rccl_collectives_world1():
 
 
 @pytest.mark.gpu
+def test_cg_flag_schedule_agrees_across_ranks_with_different_histories_world2():
+    _run("cghist", 2)
+
+
+@pytest.mark.gpu
 def test_row_sharded_cholesky_world2():
     _run("cholrows", 2)
 
@@ -123,3 +128,36 @@ def test_row_sharded_cholesky_world2():
 @pytest.mark.gpu
 def test_row_sharded_cholesky_world3():
     _run("cholrows", 3)
+
+
+def _bench(extra, env_extra=None, timeout=300):
+    import json
+    env = dict(os.environ)
+    env.pop("WORLD_SIZE", None)
+    env.pop("RANK", None)
+    env.pop("LOCAL_RANK", None)
+    env.update(env_extra or {})
+    res = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py")] + extra,
+                         env=env, capture_output=True, text=True, timeout=timeout)
+    assert res.returncode == 0, res.stdout[-1500:] + "\n" + res.stderr[-3000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    return json.loads(lines[0])
+
+
+@pytest.mark.gpu
+def test_bench_started_bare_launches_its_own_ranks():
+    """`python bench.py --gpus 2` with no torchrun environment spawns its ranks itself (child
+    torchrun, before any GPU call) and prints ONE line that agrees with the single-GPU line on
+    the workload (the reference's `mpirun -n N python example.py`, example.py:161-174)."""
+    common = ["--config", "c1", "--steps", "2", "--warmup", "1", "--no-cpu"]
+    one = _bench(["--gpus", "1"] + common)
+    two = _bench(["--gpus", "2"] + common, {"HYDRA_DIST_BACKEND": "gloo"})
+    assert one["n_gpus"] == 1 and two["n_gpus"] == 2
+    assert two["config"]["rows_M"] == one["config"]["rows_M"] == 45 * 16 * 20
+    assert two["config"]["workload"] == one["config"]["workload"]
+    for line in (one, two):
+        assert line["value"] > 0 and line["sample_rel_residual"] < 1e-8
+        assert line["steps"] == 2 and line["warmup"] == 1
+    # under torchrun's environment the same file is a rank and does not spawn again
+    assert "freq-sharded x2" in two["config"]["parallelism"]

@@ -386,6 +386,80 @@ def test_dense_fallback_matches_scipy(hy):
         hy.linear_solver.solve_dense(-np.eye(4), np.ones(4))
 
 
+@pytest.mark.parametrize("ns,factored_proj", [(40, True), (40, False), (6146, True)])
+def test_system_cache_reuses_operator_and_factor_bit_for_bit(hy, orc, ns, factored_proj):
+    """precompute_mpi(cache=) + cache.solve: while gains / noise weights / prior are unchanged the
+    operator and its Cholesky factor are reused (the reference rebuilds them every iteration,
+    example.py:878,944) and every sample is BIT-identical to the rebuilding path with the same
+    fluctuation vectors; a change of the gains rebuilds.  6146 sources: the matrix-core
+    factorisation (n >= 6144), whose in-place factor leaves the operator readable above the
+    diagonal (cache.matvec)."""
+    import torch
+    from hydra_amd import _dev, linear_solver, ptsrc_sampler
+    ant_pos, antpairs, ra, dec, freqs, times, fluxes = _setup(ns=ns, nf=2, nt=3)
+    nant, nbl = len(ant_pos), len(antpairs)
+    ants = np.arange(nant)
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    proj = hy.ptsrc_sampler.calc_proj_operator(ra, dec, _dev.f64(fluxes), ant_pos, antpairs, freqs,
+                                               times, bh, materialize=not factored_proj)
+    rng = np.random.RandomState(3)
+    shape = (nbl, 2, 3)
+    g = _dev.c128((1.0 + 0.5j) + 0.1 * (rng.randn(nant, 2, 3) + 1j * rng.randn(nant, 2, 3)))
+    w = _dev.f64(np.full(shape, 4.0))
+    data = _dev.c128(rng.randn(*shape) + 1j * rng.randn(*shape))
+    prior = _dev.f64(0.1 + 0.05 * rng.rand(ns))
+
+    def omegas(k):
+        r = np.random.RandomState(100 + k)
+        return (_dev.c128((r.randn(*shape) + 1j * r.randn(*shape)) / np.sqrt(2)), _dev.f64(r.randn(ns)))
+
+    def rebuild(gains, k):
+        om_n, om_a = omegas(k)
+        A, b = ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, proj, data, w, gains,
+                                            prior, omega_n=om_n, omega_a=om_a)
+        return A, b, linear_solver.solve_dense(A, b)
+
+    cache = ptsrc_sampler.SystemCache()
+
+    def cached(gains, k):
+        om_n, om_a = omegas(k)
+        A, b = ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, proj, data, w, gains,
+                                            prior, omega_n=om_n, omega_a=om_a, cache=cache)
+        return A, b, cache.solve(b)
+
+    for k in range(3):                                   # one build, then two reuses
+        A0, b0, x0 = rebuild(g, k)
+        A1, b1, x1 = cached(g.clone(), k)                # a NEW tensor with the same values
+        assert torch.equal(b0, b1) and torch.equal(x0, x1), k
+        assert relerr(cache.matvec(x1).cpu().numpy(), (A0 @ x0).cpu().numpy()) < 1e-13
+    assert (cache.misses, cache.hits) == (1, 2) and cache.factored
+    # the upper triangle of the cached operator is still the operator
+    assert torch.equal(torch.triu(A1, 1), torch.triu(A0, 1))
+    assert not getattr(A1, "hydra_symmetric", False)
+    g2 = g * 1.01                                        # the gain head moved: rebuild
+    A0, b0, x0 = rebuild(g2, 7)
+    A1, b1, x1 = cached(g2, 7)
+    assert (cache.misses, cache.hits) == (2, 2)
+    assert torch.equal(torch.triu(A0, 1), torch.triu(A1, 1)) and torch.equal(cache.diag, A0.diagonal())
+    assert torch.equal(b0, b1) and torch.equal(x0, x1)
+    w2 = w.clone()
+    w2[1, 0, 2] = 0.0                                    # a flag appeared: rebuild
+    om_n, om_a = omegas(9)
+    ptsrc_sampler.precompute_mpi(None, ants, antpairs, freqs, times, proj, data, w2, g2, prior,
+                                 omega_n=om_n, omega_a=om_a, cache=cache)
+    assert (cache.misses, cache.hits) == (3, 2)
+    # against the oracle once (the cache must not have changed what is computed)
+    if ns == 40:
+        bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+        R = orc.ptsrc.calc_proj_operator(ra, dec, fluxes, ant_pos, antpairs, freqs, times, bo)
+        A_ref, b_ref = orc.ptsrc.precompute(ants, antpairs, R, data.cpu().numpy(), w.cpu().numpy(),
+                                            g2.cpu().numpy(), prior.cpu().numpy(),
+                                            omega_n=omegas(7)[0].cpu().numpy(),
+                                            omega_a=omegas(7)[1].cpu().numpy())
+        assert operr(b0.cpu().numpy(), b_ref) < OP_TOL
+        assert relerr(x0.cpu().numpy(), orc.ptsrc.dense_solve(A_ref, b_ref)) < SAMPLE_TOL
+
+
 # ------------------------------------------------------------------ gains helper
 
 def test_operator_cg_reads_the_flag_on_a_learned_schedule(hy):
