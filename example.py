@@ -251,6 +251,9 @@ def main(argv=None, on_head=None):
     current_model = model0_chunk.clone()
     x_soln = torch.zeros(Nptsrc, dtype=torch.float64, device=dev)
     mpicg_groups = None
+    # the source head's operator and its Cholesky factor change only with the gains (and the noise
+    # weights / prior): kept between iterations, rebuilt when the gain head has moved
+    source_cache = hydra.ptsrc_sampler.SystemCache() if args.solver_name != "mpicg" else None
     if args.sample_sh:
         inv_prior_sh = torch.full((nmodes_sh,), 1.0 / args.sh_prior_std ** 2, dtype=torch.float64,
                                   device=dev)
@@ -332,7 +335,8 @@ def main(argv=None, on_head=None):
             source_op, source_rhs = hydra.ptsrc_sampler.precompute_mpi(
                 comm, ants=ants, antpairs=antpairs, freq_chunk=freq_chunk, time_chunk=time_chunk,
                 proj_chunk=source_proj, data_chunk=resid, inv_noise_var_chunk=inv_noise_var_chunk,
-                gain_chunk=g_now, amp_prior_std=amp_prior_std, realisation=True)
+                gain_chunk=g_now, amp_prior_std=amp_prior_std, realisation=True,
+                cache=source_cache)
             if args.solver_name == "mpicg" and comm is not None and ngrid > 0:
                 # sqrt(N) x sqrt(N) blocks of the operator, one per worker (example.py:899-938)
                 shape = comm.bcast(tuple(source_op.shape), root=0)
@@ -351,9 +355,9 @@ def main(argv=None, on_head=None):
             elif myid == 0:
                 if args.solver_name == "mpicg":           # a single worker: the same CG, x0 = 0
                     x_soln = hydra.linear_solver.cg(source_op, source_rhs)
-                else:     # the reference's dense solve, whatever the solver's name (:940-947)
-                    x_soln = hydra.linear_solver.solve_dense(source_op, source_rhs,
-                                                             overwrite_a=True)
+                else:     # the reference's dense solve, whatever the solver's name (:940-947);
+                    # factored on the first iteration after the gains changed, reused otherwise
+                    x_soln = source_cache.solve(source_rhs)
             if myid == 0:
                 x_soln = x_soln * amp_prior_std           # we solved for x = S^-1/2 s
                 np.save(os.path.join(out, "src_amp_%05d" % n), x_soln.cpu().numpy())

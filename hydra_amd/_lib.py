@@ -15,6 +15,8 @@ import re
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
 HEADER = os.path.join(os.path.dirname(_HERE), "include", "hydra_hip.h")
+#: measurement / test hooks, declared apart from the product boundary
+DIAG_HEADER = os.path.join(os.path.dirname(_HERE), "include", "hydra_hip_diag.h")
 LIBRARY = os.environ.get("HYDRA_HIP_LIBRARY", os.path.join(_HERE, "libhydra_hip.so"))
 
 _CTYPE = {
@@ -68,10 +70,13 @@ def prototypes():
     global _protos
     if _protos is None:
         _protos = _parse_header()
+        _protos.update(_parse_header(DIAG_HEADER))
     return _protos
 
 
-def declared_symbols():
+def declared_symbols(product_only=False):
+    if product_only:
+        return sorted(_parse_header().keys())
     return sorted(prototypes().keys())
 
 

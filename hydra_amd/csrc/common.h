@@ -6,6 +6,7 @@
 #include <string.h>
 
 #include "../../include/hydra_hip.h"
+#include "../../include/hydra_hip_diag.h"
 
 namespace hydra {
 

@@ -232,11 +232,6 @@ int hydra_flagged_rows(const double* V, int nf, int nt, int nant, int ns, const 
 int hydra_gram_subtract(double* G, const double* C, int ns, const double* prior_std,
                         const double* add_diag, void* stream);
 
-/* Profiling hook: HIP events (hipEvent_t, NULL to clear) recorded by this thread's next calls of
- * hydra_gram_fused / hydra_gram_uniform on their stream immediately before and after the main
- * Gram kernel.  No counterpart in the reference.                                            */
-int hydra_profile_events(void* start_event, void* stop_event);
-
 /* ---- operator application (RHS, matrix-free LHS, model update) ------------------- */
 
 /* out[r] = rowmul[r] * sum_s R[r,s] x[s]   (M) c128; x (Ns) f64; rowmul (M) c128 or NULL
@@ -283,11 +278,6 @@ int hydra_adjoint_V_antspace(const double* V, int nf, int nt, int nant, int ns, 
                              const int32_t* bl_j, int nbl, const double* z, const double* scale,
                              const double* add, double* out, void* workspace,
                              size_t workspace_bytes, void* stream);
-/* Test hook: hydra_adjoint_V forms R^H z in antenna space on the matrix cores when Nant <= 64
- * (default) and with the pair-loop kernel otherwise; enable = 0 forces the pair loop.  Returns the
- * previous setting.  No counterpart in the reference.                                        */
-int hydra_debug_adjoint_mfma(int enable);
-
 /* GCR right-hand-side row term:
  *   z[r] = conj(gg[r]) * ( (data[r] - model[r]) * w[r] + omega_n[r] * sqrt(w[r]) )
  * model may be NULL (=0), gg NULL (=1), omega_n NULL (=0).

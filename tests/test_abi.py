@@ -27,6 +27,10 @@ def test_library_exports_every_declared_symbol():
     exported = set(re.findall(r" T (hydra_[A-Za-z0-9_]+)", out))
     assert exported == set(declared), exported ^ set(declared)
     assert lib.hydra_abi_version() == 1
+    # measurement / test hooks are declared apart from the product boundary
+    product = set(_lib.declared_symbols(product_only=True))
+    assert set(declared) - product == {"hydra_profile_events", "hydra_debug_adjoint_mfma"}
+    assert not any("debug" in n or "profile" in n for n in product)
 
 
 def test_header_is_plain_c_and_cites_the_reference():
