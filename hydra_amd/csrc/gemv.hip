@@ -426,6 +426,134 @@ apply_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int n
   }
 }
 
+// ---- the same product for MORE than 144 antennas (HERA-350: 22 block rows, 253 upper blocks) ----
+// Neither the blocks of C (3 accumulators each) fit the registers of one workgroup nor 32 sources of
+// all antennas two LDS buffers, so the grid gets a third dimension: a workgroup owns one SUPER-BLOCK
+// of C -- 4 x 4 blocks = 64 row antennas x 64 column antennas, on or above the super-block diagonal
+// -- of one (f,t) and source range, and stages the voltages of those 128 antennas only (rows 0-63 of
+// the LDS tile: the row antennas, 64-127: the column antennas; two buffers of 64 KiB + x).  Each of
+// the 8 waves takes two of the (up to) 16 blocks.  Staging, swizzle, k-step and the 3-product complex
+// multiply are apply_V_big_kernel's.  The super-block index is the fastest grid axis, so the 21
+// workgroups that read the same voltages run at the same time and all but the first find them in
+// the memory-side cache.
+constexpr int AVS_SB = 4;                      // blocks per super-block edge
+constexpr int AVS_ROWS = 2 * 16 * AVS_SB;      // rows of an LDS tile
+
+__global__ void __launch_bounds__(AVB_THREADS)
+apply_V_sb_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int nr,
+                  const double* __restrict__ x, int nsplit, int tiles_per_split, int nsr,
+                  f64x2* __restrict__ Cmat) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  constexpr int tile_bytes = AVS_ROWS * AVB_SRC * 16 + AVB_SRC * 16;   // voltages, then x
+  const int nap = 16 * nr;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, g = lane >> 4;
+  const int nsb = nsr * (nsr + 1) / 2;
+  const int sb = blockIdx.x % nsb, rest = blockIdx.x / nsb;
+  const int sp = rest % nsplit, ft = rest / nsplit;
+  int sI = 0, sJ;
+  {
+    int base = 0;
+    while (sI + 1 < nsr && base + (nsr - sI) <= sb) { base += nsr - sI; ++sI; }
+    sJ = sI + (sb - base);
+  }
+  const int ntile = (ns + AVB_SRC - 1) / AVB_SRC;
+  const int t0 = sp * tiles_per_split, t1 = min(t0 + tiles_per_split, ntile);
+
+  // this wave's two blocks: entries 2 wave, 2 wave + 1 of the super-block's list of blocks that
+  // exist (inside the array, on or above the block diagonal)
+  int brl[2] = {-1, -1}, bcl[2] = {0, 0};
+  {
+    int cnt = 0;
+    for (int c = 0; c < AVS_SB * AVS_SB; ++c) {
+      const int rbl = c / AVS_SB, cbl = c % AVS_SB;
+      const int rb = AVS_SB * sI + rbl, cb = AVS_SB * sJ + cbl;
+      if (rb < nr && cb < nr && cb >= rb) {
+        if (cnt == 2 * wave) { brl[0] = rbl; bcl[0] = cbl; }
+        if (cnt == 2 * wave + 1) { brl[1] = rbl; bcl[1] = cbl; }
+        ++cnt;
+      }
+    }
+  }
+
+  const f64x2* vft = V + (size_t)ft * nant * ns;
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)smem);
+  auto stage = [&](int t, int buf) {
+    const int s0 = t * AVB_SRC;
+    for (int q = wave; q < AVS_ROWS / 2; q += 8) {
+      const int row = 2 * q + (lane >> 5);
+      const int a = min((row < 16 * AVS_SB ? 16 * AVS_SB * sI + row : 16 * AVS_SB * (sJ - 1) + row), nant - 1);
+      const int sl = (lane & 31) ^ (row & 15);
+      const unsigned off = (unsigned)min(s0 + sl, ns - 1) * 16u;
+      const char* src = reinterpret_cast<const char*>(vft);
+      const unsigned long long rowoff = (unsigned long long)a * ns * 16ull + off;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * tile_bytes + q * 1024));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off"
+                   :: "s"(dst), "v"(src + rowoff) : "memory");
+    }
+    if (wave == 0 && x) {
+      const long long dw = min((long long)s0 * 2 + lane, 2LL * ns - 1);
+      const char* src = reinterpret_cast<const char*>(x) + dw * 4;
+      const unsigned dst = __builtin_amdgcn_readfirstlane(
+          lds_base + (unsigned)(buf * tile_bytes + AVS_ROWS * AVB_SRC * 16));
+      asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dword %1, off"
+                   :: "s"(dst), "v"(src) : "memory");
+    }
+  };
+
+  f64x4 p1[2], p2[2], p3[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    p1[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    p2[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+    p3[q] = f64x4{0.0, 0.0, 0.0, 0.0};
+  }
+  int ra[2], rc[2];
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    ra[q] = max(brl[q], 0) * 16 + lr;
+    rc[q] = 16 * AVS_SB + bcl[q] * 16 + lr;
+  }
+  if (t0 < t1) stage(t0, 0);
+  for (int t = t0; t < t1; ++t) {
+    const int buf = (t - t0) & 1;
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();                       // tile t has landed; the other buffer is free
+    if (t + 1 < t1) stage(t + 1, buf ^ 1);
+    const unsigned char* tb = smem + buf * tile_bytes;
+    const double* xs = reinterpret_cast<const double*>(tb + AVS_ROWS * AVB_SRC * 16);
+    const int s0 = t * AVB_SRC;
+#pragma unroll 4
+    for (int k = 0; k < AVB_SRC / 4; ++k) {
+      const int sl = 4 * k + g;
+      double xv = x ? xs[sl] : 1.0;
+      if (s0 + sl >= ns) xv = 0.0;
+#pragma unroll
+      for (int q = 0; q < 2; ++q) {
+        const f64x2 av = *reinterpret_cast<const f64x2*>(tb + (ra[q] * AVB_SRC + (sl ^ lr)) * 16);
+        const f64x2 bv = *reinterpret_cast<const f64x2*>(tb + (rc[q] * AVB_SRC + (sl ^ lr)) * 16);
+        const double ax = av.x * xv, ay = av.y * xv;
+        p1[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax, bv.x, p1[q], 0, 0, 0);
+        p2[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ay, bv.y, p2[q], 0, 0, 0);
+        p3[q] = __builtin_amdgcn_mfma_f64_16x16x4f64(ax - ay, bv.x + bv.y, p3[q], 0, 0, 0);
+      }
+    }
+  }
+  f64x2* cm = Cmat + ((size_t)sp * nft + ft) * nap * nap;
+#pragma unroll
+  for (int q = 0; q < 2; ++q) {
+    if (brl[q] >= 0) {
+      const int rb = AVS_SB * sI + brl[q], cb = AVS_SB * sJ + bcl[q];
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        cm[(size_t)(rb * 16 + g + 4 * e) * nap + cb * 16 + lr] =
+            f64x2{p1[q][e] + p2[q][e], p3[q][e] - p1[q][e] + p2[q][e]};
+    }
+  }
+}
+
 // out[b,ft] = rowmul[b,ft] * sum_split C[split][ft][i_b][j_b]; entries below the block diagonal
 // are the conjugates of the stored upper blocks
 __global__ void __launch_bounds__(256)
@@ -990,6 +1118,154 @@ adjoint_V_big_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int
   }
 }
 
+// ---- R^H z in antenna space for arrays of more than 160 antennas (HERA-350) ---------------------
+// Two 32-source tiles of ALL antennas no longer fit the LDS (350 antennas: 2 x 176 KiB), so the grid
+// gets a third dimension here too: a workgroup owns a SUPER-ROW of Zc -- 4 row blocks = 64 antennas,
+// one per multiplying wave -- for its 32 sources and (f,t) range, and walks the super-columns
+// K = I .. nsr-1 on and right of the diagonal; the voltages of the 64 antennas of super-column K
+// (32 KiB) are double-buffered in LDS by the staging wave, one barrier per tile.  W_i = sum_k Zc[i][k]
+// V_k accumulates in the wave's registers over the tiles of an (f,t); then Re(V_i conj(W_i)) with V_i
+// re-read from global memory (8 loads per lane and (f,t): the tile that held them is gone).  The Zc
+// fragments are adjbig_frag_kernel's; the fragments of the NEXT group of four k-steps are fetched
+// (global memory / L2) while the current group multiplies, across tile and (f,t) boundaries.
+// Super-column K's voltages are read once per super-row I <= K: (nsr + 1) / 2 times on average,
+// mostly from the memory-side cache (workgroups of equal source tile and (f,t) range differ in
+// blockIdx.z only).
+constexpr int AS_SB = 4;                       // row blocks per super-row = multiplying waves
+
+__global__ void __launch_bounds__(AB_THREADS)
+adjoint_V_sb_kernel(const f64x2* __restrict__ V, int nft, int nant, int ns, int nr,
+                    const f64x2* __restrict__ zri, const double* __restrict__ zs, int ft_per_split,
+                    int nsr, double* __restrict__ partial) {
+  __shared__ __align__(16) f64x2 s_v[2][16 * AS_SB * AB_SRC];          // 2 x 32 KiB
+  double* s_red = reinterpret_cast<double*>(&s_v[0][0]);               // [16][AB_SRC], after the loop
+  const int nk = 4 * nr, nsteps = adjbig_prefix(nr, nk);
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int kr = lane >> 4, lc = lane & 15;
+  const int s0 = blockIdx.x * AB_SRC;
+  const int ft0 = blockIdx.y * ft_per_split, ft1 = min(ft0 + ft_per_split, nft);
+  const int sI = nsr - 1 - (int)blockIdx.z;      // the long super-rows are handed out first
+  const int rb = AS_SB * sI + wave;              // this wave's row block (waves 0-3)
+  const bool active = wave < AS_SB && rb < nr;
+
+  const unsigned lane_off = (unsigned)min(s0 + (lane & 31), ns - 1) * 16u;
+  const unsigned voff2 = lane_off + (unsigned)(lane >> 5) * (unsigned)ns * 16u;   // two rows
+  const unsigned lds_base = __builtin_amdgcn_readfirstlane(
+      (unsigned)(size_t)(__attribute__((address_space(3))) void*)&s_v[0][0]);
+  const size_t row_bytes = (size_t)ns * 16;
+  auto stage = [&](int ft, int K, int buf) {
+    const char* vft = reinterpret_cast<const char*>(V + (size_t)ft * nant * ns);
+    unsigned dst = __builtin_amdgcn_readfirstlane(lds_base + (unsigned)(buf * 16 * AS_SB * AB_SRC * 16));
+    const int a0 = 16 * AS_SB * K;
+    for (int q = 0; q < 8 * AS_SB; ++q) {          // 32 pieces of 2 rows x 32 sources
+      const int a = a0 + 2 * q;
+      if (a + 1 < nant) {
+        const char* src = vft + (size_t)a * row_bytes;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(voff2), "s"(src) : "memory");
+      } else {          // rows beyond Nant repeat an existing row: they only meet zeros of Zc
+        const char* src = vft + (size_t)min(a, nant - 1) * row_bytes;
+        asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, %2"
+                     :: "s"(dst), "v"(lane_off), "s"(src) : "memory");
+      }
+      dst += 2 * AB_SRC * 16;
+    }
+  };
+
+  struct ZS {
+    f64x2 z[4];
+    double s[4];
+  };
+  // fragments of the group (= column block kb) of row block rb at (f,t) ft
+  auto load_zs = [&](ZS& o, int ft, int kb) {
+    const size_t step0 = (size_t)ft * nsteps + adjbig_prefix(rb, nk) + 4 * (kb - rb);
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      o.z[u] = zri[(step0 + u) * 64 + lane];
+      o.s[u] = zs[(step0 + u) * 64 + lane];
+    }
+  };
+
+  double acc[2] = {0.0, 0.0};
+  ZS cur, nxt;
+  if (active && ft0 < ft1) load_zs(cur, ft0, rb);
+  if (wave == AS_SB && ft0 < ft1) stage(ft0, sI, 0);
+  int tile = 0;
+  for (int ft = ft0; ft < ft1; ++ft) {
+    f64x4 p1[2], p2[2], p3[2];
+#pragma unroll
+    for (int c = 0; c < 2; ++c) {
+      p1[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+      p2[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+      p3[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+    }
+    for (int K = sI; K < nsr; ++K, ++tile) {
+      const int buf = tile & 1;
+      if (wave == AS_SB) asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __syncthreads();                    // this tile has landed; the other buffer is free
+      if (wave == AS_SB) {
+        if (K + 1 < nsr) stage(ft, K + 1, buf ^ 1);
+        else if (ft + 1 < ft1) stage(ft + 1, sI, buf ^ 1);
+        continue;
+      }
+      if (!active) continue;
+      const f64x2* vb = &s_v[buf][0];
+      const int kb0 = max(AS_SB * K, rb), kb1 = min(AS_SB * K + AS_SB, nr);
+      for (int kb = kb0; kb < kb1; ++kb) {
+        // the group after this one: next column block, next tile, or next (f,t)
+        int nft_ = ft, nkb = kb + 1;
+        if (nkb >= nr) { nkb = rb; nft_ = (ft + 1 < ft1) ? ft + 1 : ft; }
+        load_zs(nxt, nft_, nkb);
+        const f64x2* vp = vb + (size_t)(16 * (kb - AS_SB * K) + kr) * AB_SRC + lc;
+        f64x2 v0[4], v1[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          v0[u] = vp[(size_t)u * 4 * AB_SRC];
+          v1[u] = vp[(size_t)u * 4 * AB_SRC + 16];
+        }
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const double s0v = v0[u].x + v0[u].y, s1v = v1[u].x + v1[u].y;
+          p1[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z[u].x, v0[u].x, p1[0], 0, 0, 0);
+          p1[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z[u].x, v1[u].x, p1[1], 0, 0, 0);
+          p2[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z[u].y, v0[u].y, p2[0], 0, 0, 0);
+          p2[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.z[u].y, v1[u].y, p2[1], 0, 0, 0);
+          p3[0] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.s[u], s0v, p3[0], 0, 0, 0);
+          p3[1] = __builtin_amdgcn_mfma_f64_16x16x4f64(cur.s[u], s1v, p3[1], 0, 0, 0);
+        }
+        cur = nxt;
+      }
+    }
+    if (active) {
+      // Re(V_i conj(W_i)) for the rows this lane holds: antenna 16 rb + kr + 4 g
+      const f64x2* vft = V + (size_t)ft * nant * ns;
+#pragma unroll
+      for (int c = 0; c < 2; ++c)
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int a = 16 * rb + kr + 4 * g;
+          const f64x2 vv = vft[(size_t)min(a, nant - 1) * ns + min(s0 + 16 * c + lc, ns - 1)];
+          const double wre = p1[c][g] - p2[c][g];
+          const double wim = p3[c][g] - p1[c][g] - p2[c][g];
+          if (a < nant) acc[c] += vv.x * wre + vv.y * wim;
+        }
+    }
+  }
+  __syncthreads();                         // everyone is done with the voltage tiles
+  if (wave < AS_SB) {
+    s_red[(wave * 4 + kr) * AB_SRC + lc] = acc[0];
+    s_red[(wave * 4 + kr) * AB_SRC + 16 + lc] = acc[1];
+  }
+  __syncthreads();
+  if (tid < AB_SRC && s0 + tid < ns) {
+    double t = 0.0;
+#pragma unroll
+    for (int q = 0; q < 16; ++q) t += s_red[q * AB_SRC + tid];
+    partial[((size_t)blockIdx.z * gridDim.y + blockIdx.y) * ns + s0 + tid] = t;
+  }
+}
+
 static void adjoint_V_plan(int nft, int ns, int* nsplit, int* per) {
   int chunks = (ns + 63) / 64;   // (sized for the 64-wide kernel; the 16-wide one just has more chunks)
   int want = std::max(1, std::min(nft, 2048 / chunks));
@@ -1119,8 +1395,27 @@ static void apply_V_big_plan(int nft, int ns, int* nsplit, int* tiles_per_split)
   *nsplit = (ntile + *tiles_per_split - 1) / *tiles_per_split;
 }
 
+// the same for apply_V_sb_kernel, whose grid also runs over the super-blocks
+static void apply_V_sb_plan(int nft, int ns, int nsb, int* nsplit, int* tiles_per_split) {
+  const int ntile = (ns + AVB_SRC - 1) / AVB_SRC;
+  int want = 1;
+  while (want < 64 && (long long)nft * nsb * want < 2048 && ntile / (2 * want) >= 8) want *= 2;
+  *tiles_per_split = (ntile + want - 1) / want;
+  *nsplit = (ntile + *tiles_per_split - 1) / *tiles_per_split;
+}
+
+static constexpr int APPLY_V_BIG_MAX_NANT = 144;     // two LDS tiles of all antennas x 32 sources
+static constexpr int APPLY_V_SB_MAX_NANT = 1024;     // super-block form: 32-bit offsets, table sizes
+
 size_t hydra_apply_V_workspace_bytes(int nf, int nt, int nant, int ns) {
-  if (nf <= 0 || nt <= 0 || nant <= 0 || ns <= 0 || nant > 144) return 0;
+  if (nf <= 0 || nt <= 0 || nant <= 0 || ns <= 0 || nant > APPLY_V_SB_MAX_NANT) return 0;
+  if ((size_t)nant * ns * 16 >= ((size_t)1 << 32)) return 0;   // 32-bit offsets inside one (f,t)
+  if (nant > APPLY_V_BIG_MAX_NANT) {
+    const int nr = (nant + 15) / 16, nsr = (nr + AVS_SB - 1) / AVS_SB;
+    int nsplit, tps;
+    apply_V_sb_plan(nf * nt, ns, nsr * (nsr + 1) / 2, &nsplit, &tps);
+    return (size_t)nsplit * nf * nt * (16 * nr) * (16 * nr) * 16;
+  }
   if (nant > 64) {
     int nsplit, tps;
     apply_V_big_plan(nf * nt, ns, &nsplit, &tps);
@@ -1147,6 +1442,25 @@ int hydra_apply_V(const double* V, int nf, int nt, int nant, int ns, const int32
                 workspace_bytes, need);
   int nft = nf * nt, nsplit, kps;
   int nr = (nant + 15) / 16;
+  if (nant > APPLY_V_BIG_MAX_NANT) {
+    const int nsr = (nr + AVS_SB - 1) / AVS_SB, nsb = nsr * (nsr + 1) / 2;
+    int tps;
+    apply_V_sb_plan(nft, ns, nsb, &nsplit, &tps);
+    HYDRA_CHECK_ARG((long long)nft * nsplit * nsb <= 2147483647LL, "hydra_apply_V: too many (f,t)");
+    const size_t lds = 2 * ((size_t)AVS_ROWS * AVB_SRC * 16 + AVB_SRC * 16);
+    hipStream_t st = as_stream(stream);
+    f64x2* cm = static_cast<f64x2*>(workspace);
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&apply_V_sb_kernel), lds)) return rc;
+    apply_V_sb_kernel<<<(unsigned)(nft * nsplit * nsb), AVB_THREADS, lds, st>>>(
+        reinterpret_cast<const f64x2*>(V), nft, nant, ns, nr, x, nsplit, tps, nsr, cm);
+    HYDRA_CHECK_LAUNCH("hydra_apply_V(antenna space, super-blocks)");
+    size_t n = (size_t)nbl * nft;
+    apply_V_gather_kernel<<<(unsigned)std::min<size_t>((n + 255) / 256, 8192), 256, 0, st>>>(
+        cm, nft, nr * 16, nsplit, bl_i, bl_j, nbl, reinterpret_cast<const f64x2*>(rowmul),
+        reinterpret_cast<f64x2*>(out));
+    HYDRA_CHECK_LAUNCH("hydra_apply_V(gather)");
+    return HYDRA_OK;
+  }
   if (nant > 64) {
     int tps;
     apply_V_big_plan(nft, ns, &nsplit, &tps);
@@ -1213,6 +1527,8 @@ int hydra_vis_regions(const double* V, int nf, int nt, int nant, int ns, const i
                         out, seg, nreg, stream);
 }
 
+static constexpr int ADJ_BIG_MAX_NAP = 160;     // adjoint_V_big_kernel: two tiles of all antennas in LDS
+
 static void adjbig_plan(int nft, int ns, int* nsplit, int* per) {
   int tiles = (ns + AB_SRC - 1) / AB_SRC;
   int want = std::max(1, std::min(nft, 2048 / std::max(tiles, 1)));
@@ -1226,7 +1542,9 @@ size_t hydra_adjoint_V_antspace_workspace_bytes(int nf, int nt, int nant, int nb
   adjbig_plan(nft, ns, &nsplit, &per);
   const int nr = (nant + 15) / 16, nk = 4 * nr, nap = 16 * nr;
   const size_t nsteps = (size_t)adjbig_prefix(nr, nk);
-  return align_up((size_t)nsplit * ns * sizeof(double), 256) +          // partial sums
+  const size_t nsr = (nr + AS_SB - 1) / AS_SB;      // partial sums per super-row above 160 antennas
+  const size_t nparts = (size_t)nsplit * (nap > ADJ_BIG_MAX_NAP ? nsr : 1);
+  return align_up(nparts * ns * sizeof(double), 256) +                  // partial sums
          align_up((size_t)nft * nbl * 16, 256) +                        // z transposed
          align_up((size_t)nap * nap * sizeof(int32_t), 256) +           // pair table
          align_up((size_t)nft * nsteps * 64 * 16, 256) +                // Zc fragments (re, im)
@@ -1240,9 +1558,9 @@ int hydra_adjoint_V_antspace(const double* V, int nf, int nt, int nant, int ns, 
   HYDRA_CHECK_ARG(V && bl_i && bl_j && z && out && nf > 0 && nt > 0 && nant > 0 && ns > 0 && nbl > 0,
                   "hydra_adjoint_V_antspace: bad arguments");
   const int nr = (nant + 15) / 16, nk = 4 * nr, nap = 16 * nr;
+  const bool super_rows = nap > ADJ_BIG_MAX_NAP;
   const size_t lds = std::max<size_t>((size_t)2 * nap * AB_SRC * 16, (size_t)16 * AB_SRC * 8);
-  HYDRA_CHECK_ARG(lds <= 160 * 1024, "hydra_adjoint_V_antspace: nant=%d exceeds the LDS tile (160)",
-                  nant);
+  HYDRA_CHECK_ARG(nant <= 1024, "hydra_adjoint_V_antspace: nant=%d exceeds the table limit (1024)", nant);
   HYDRA_CHECK_ARG((size_t)nant * ns * 16 < ((size_t)1 << 32),
                   "hydra_adjoint_V_antspace: one (f,t) slice of V must be below 4 GiB");
   size_t need = hydra_adjoint_V_antspace_workspace_bytes(nf, nt, nant, nbl, ns);
@@ -1254,8 +1572,10 @@ int hydra_adjoint_V_antspace(const double* V, int nf, int nt, int nant, int ns, 
   HYDRA_CHECK_ARG(nsplit <= 65535, "hydra_adjoint_V_antspace: too many splits");
   const int nsteps = adjbig_prefix(nr, nk);
   unsigned char* w = static_cast<unsigned char*>(workspace);
+  const int nsr = (nr + AS_SB - 1) / AS_SB;
+  const size_t nparts = (size_t)nsplit * (super_rows ? nsr : 1);
   double* partial = reinterpret_cast<double*>(w);
-  w += align_up((size_t)nsplit * ns * sizeof(double), 256);
+  w += align_up(nparts * ns * sizeof(double), 256);
   f64x2* zt = reinterpret_cast<f64x2*>(w);
   w += align_up((size_t)nft * nbl * 16, 256);
   int32_t* tab = reinterpret_cast<int32_t*>(w);
@@ -1272,12 +1592,18 @@ int hydra_adjoint_V_antspace(const double* V, int nf, int nt, int nant, int ns, 
   adjbig_frag_kernel<<<dim3((nsteps + 3) / 4, std::min(nft, 4096)), 256, 0, st>>>(
       zt, tab, nbl, nft, nr, nsteps, zri, zs);
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V_antspace(fragments)");
-  if (int rc = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_big_kernel), lds)) return rc;
-  dim3 grid((ns + AB_SRC - 1) / AB_SRC, nsplit);
-  adjoint_V_big_kernel<<<grid, AB_THREADS, lds, st>>>(reinterpret_cast<const f64x2*>(V), nft, nant, ns, nr,
-                                               zri, zs, per, partial);
+  if (super_rows) {
+    dim3 grid((ns + AB_SRC - 1) / AB_SRC, nsplit, nsr);
+    adjoint_V_sb_kernel<<<grid, AB_THREADS, 0, st>>>(reinterpret_cast<const f64x2*>(V), nft, nant, ns,
+                                                     nr, zri, zs, per, nsr, partial);
+  } else {
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&adjoint_V_big_kernel), lds)) return rc;
+    dim3 grid((ns + AB_SRC - 1) / AB_SRC, nsplit);
+    adjoint_V_big_kernel<<<grid, AB_THREADS, lds, st>>>(reinterpret_cast<const f64x2*>(V), nft, nant, ns,
+                                                        nr, zri, zs, per, partial);
+  }
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V_antspace");
-  adjoint_reduce_kernel<<<(ns + 255) / 256, 256, 0, st>>>(partial, nsplit, ns, scale, add, out);
+  adjoint_reduce_kernel<<<(ns + 255) / 256, 256, 0, st>>>(partial, (int)nparts, ns, scale, add, out);
   HYDRA_CHECK_LAUNCH("hydra_adjoint_V_antspace(reduce)");
   return HYDRA_OK;
 }

@@ -124,9 +124,11 @@ class FactoredProj:
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
         out = _dev.empty((ns,), torch.float64)
-        if 64 < nant <= 160 and self.unique_upper and self.antspace_adjoint:
+        if (64 < nant <= 1024 and self.unique_upper and self.antspace_adjoint
+                and nant * ns * 16 < (1 << 32)):
             # more than 64 antennas: antenna space on the matrix cores (csrc/gemv.hip,
-            # adjoint_V_big_kernel) instead of the pair loop on the vector units
+            # adjoint_V_big_kernel; adjoint_V_sb_kernel beyond 160) instead of the pair loop on
+            # the vector units
             nbytes = _dev._lib.query("hydra_adjoint_V_antspace_workspace_bytes", nf, nt, nant, nbl,
                                      ns)
             ws = _dev.workspace(nbytes)

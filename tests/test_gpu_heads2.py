@@ -546,11 +546,14 @@ def test_antenna_space_apply_matches_pair_loop_and_numpy(hy, nant, ns, nf, nt, k
 
 
 @pytest.mark.parametrize("hex_spec,ns,nf,nt", [((5, 9), 77, 3, 2), ((6, 11), 100, 2, 3),
-                                               ((7, 13), 45, 1, 5), ((7, 14), 33, 2, 1)])
+                                               ((7, 13), 45, 1, 5), ((7, 14), 33, 2, 1),
+                                               ((8, 15), 50, 2, 2), ((11, 21), 70, 1, 3)])
 def test_antenna_space_adjoint_for_more_than_64_antennas(hex_spec, ns, nf, nt):
     """hydra_adjoint_V_antspace (W = Zc V on the matrix cores, any array size) against the pair
     loop and the oracle's Re(R^H z): 61, 91, 127 and 154 antennas (row blocks 4..10, odd and even
-    counts, antennas not a multiple of 16), sources not a multiple of the 32-wide tile, scale / add."""
+    counts, antennas not a multiple of 16), sources not a multiple of the 32-wide tile, scale / add;
+    169 and 331 antennas: the super-row / super-block kernels beyond one LDS tile of all antennas
+    (3 and 6 super-rows, the last one partial)."""
     import torch
     import hydra_amd as hy
     from oracle import beams as obeams, gcr_ptsrc, helpers
