@@ -521,3 +521,56 @@ def test_c3_streamed_operator_full_array_equals_resident_operator(c3):
     A_cf = op.lhs_matrix(wu, ip)
     assert float((A_cf - A_res).abs().max() / A_res.abs().max()) < 1e-11
     assert torch.equal(A_cf, A_cf.T)
+
+
+def test_streamed_sh_operator_at_hera_350():
+    """The SH head on config 5's array (350 antennas, 61 075 baselines; the north star asks for
+    every head there): StreamedSHOperator -- antenna-space R a and R^H z on the matrix cores through
+    the super-block / super-row kernels (more than 160 antennas), closed-form left-hand side --
+    against the materialised operator built by the projection kernel: application, right-hand
+    side, both left-hand-side paths, and the pair-loop kernels on the same voltages."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import _dev, sh_sampler
+    ant_pos = _c5_layout()
+    nant = len(ant_pos)
+    freqs, lsts = np.linspace(100.0, 120.0, 2), np.linspace(0.2, 0.5, 2)
+    lmax, nside = 5, 8
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    op = sh_sampler.StreamedSHOperator(freqs, lsts, bh, ant_pos, lmax, nside, latitude=LAT)
+    R, _, _ = sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside, latitude=LAT,
+                                                  as_torch=True, cross_only=True)
+    mrows, nm = R.shape
+    assert op.shape == (mrows, nm) and mrows == nant * (nant - 1) // 2 * 4 and nant == 350
+    g = torch.Generator(device=R.device).manual_seed(8)
+    a = torch.randn(nm, dtype=torch.float64, device=R.device, generator=g)
+    d = torch.randn(mrows, dtype=torch.complex128, device=R.device, generator=g)
+    om1 = torch.randn(mrows, dtype=torch.complex128, device=R.device, generator=g)
+    om0 = torch.randn(nm, dtype=torch.float64, device=R.device, generator=g)
+    a0 = 0.1 * torch.randn(nm, dtype=torch.float64, device=R.device, generator=g)
+    ip = 50.0 + 50.0 * torch.rand(nm, dtype=torch.float64, device=R.device, generator=g)
+    wu = (300.0 + 200.0 * torch.rand((1, 2, 2), dtype=torch.float64, device=R.device, generator=g)
+          ).expand(op.nbl, 2, 2).contiguous()
+
+    def rel(x, y):
+        return float(((x - y).abs().max() / y.abs().max()).item())
+
+    y_ref = (R @ a.to(torch.complex128)).reshape(op.nbl, 2, 2)
+    assert rel(op.apply(a), y_ref) < 1e-11
+    b_ref = sh_sampler.construct_rhs_no_rot(d, wu.reshape(-1), ip, om0, om1, a0, R)
+    assert rel(op.construct_rhs(d, wu, ip, om0, om1, a0), b_ref) < 1e-11
+    # the same two products through the pair loops on the vector units
+    prev = _dev._lib.query("hydra_debug_adjoint_mfma", 0)
+    op.fac.antspace_adjoint = False
+    try:
+        y_pair = op.apply(a)
+        b_pair = op.construct_rhs(d, wu, ip, om0, om1, a0)
+    finally:
+        _dev._lib.query("hydra_debug_adjoint_mfma", prev)
+        op.fac.antspace_adjoint = True
+    assert rel(op.apply(a), y_pair) < 1e-12 and rel(op.construct_rhs(d, wu, ip, om0, om1, a0), b_pair) < 1e-12
+    A_ref = sh_sampler.lhs_matrix(wu.reshape(-1), ip, R)
+    A_cf = op.lhs_matrix(wu, ip)
+    assert op.fac.last_gram_kernel == "gram_uniform_kernel"
+    assert rel(A_cf, A_ref) < 1e-10 and torch.equal(A_cf, A_cf.T)
+    assert rel(op.lhs_matrix(wu, ip, closed_form=False), A_ref) < 1e-10
