@@ -710,8 +710,16 @@ def main_gain(args, comm, rank, world, dev):
             "parallelism": f"freq-sharded x{world}" if world > 1 else "single GPU",
         },
         "sample_rel_residual": resid_rel,
-        "batched_matvec": {"vectors": batch, "ms": mv_ms,
-                           "matvecs_per_s": batch / (mv_ms * 1e-3)},
+        "batched_matvec": {
+            "vectors": batch, "ms": mv_ms, "matvecs_per_s": batch / (mv_ms * 1e-3),
+            "kernel": ("gain_pairs_mfma_kernel (per sample: symmetric weight matrix x 16 real "
+                       "columns on the FP64 matrix cores, weights in 16 x 16 antenna blocks, each "
+                       "read once per 8 vectors) between gain_basis_fwd_blocks_kernel and "
+                       "gain_basis_adj_mfma_kernel, fields sample-major"
+                       if (op.batch_mfma and op.Wb is not None) else "gain_pairs_tiled_kernel"),
+            "weights_GBps": alg_bytes / (mv_ms * 1e-3) / 1e9,
+            "frac_of_hbm_on_8M_bytes": alg_bytes / (mv_ms * 1e-3) / 1e9 / 8000.0,
+        },
         "roofline": {
             "bound": "hbm", "achieved": achieved, "peak": 8000.0, "unit": "GB/s",
             "frac": achieved / 8000.0,

@@ -810,6 +810,538 @@ gain_basis_adj_kernel(const f64x2* __restrict__ y, const f64x2* __restrict__ F,
 }
 static_assert(GA_NVAL % 8 == 0, "whole batches of 8 values");
 
+
+// ---------------------------------------------------------------------------------------------
+// Batched operator on the FP64 matrix cores (BASELINE config 4: "batched CG matvecs").
+//
+// For a batch of vectors the pair sums of one (f,t) sample are a real symmetric matrix times a
+// block of columns: T[a][j] = sum_o W[{a,o}] G[o][j], j = (vector, re / im) -- 8 vectors are the 16
+// columns of one v_mfma_f64_16x16x4_f64.  The weights are stored once more in BLOCK LAYOUT
+//   Wb[chunk of GM_FT samples][block (A <= B) of 16 x 16 antennas, row-major upper][f][a][b]
+// (zero where there is no pair; diagonal blocks symmetric with a zero diagonal; 8 % more doubles
+// than there are pairs at 331 antennas), written once per operator by gain_weights_blocks_kernel.
+//
+// A workgroup owns GM_FT samples and ALL antennas; the conjugated fields G' = conj(g) of its
+// samples sit in LDS as [f][antenna][j] (86 KiB at 331 antennas).  Block ROW X of T belongs to one
+// wave (RPW rows per wave), in registers for the whole pass.  Rounds s = 0 .. nb-1 of a round-robin
+// tournament: in round s row X meets block P = (s - X) mod nb -- an involution, so the waves that
+// own X and P are at the SAME stored block in the same round, one taking it as it is
+// (T[X] += W_XP G[P], X <= P), the other transposed (T[P] += W_XP^T G[X]): the block crosses the
+// fabric once and the second reader finds it in the CU's vector cache (a barrier per round keeps
+// the waves in step).  Either way the MFMA A operand of k-step t is 4 (direct: consecutive, one
+// 32-byte piece per lane) or 4 x 1 (transposed: 128-byte rows across 16 lanes) doubles straight
+// from global memory, fetched one round ahead; the B operand is G'[16 P + 4 g + t][j] from LDS.
+// No atomics, fixed summation order (round order).  y = g sw + conj(T) = sgn_j G' sw + T'.
+#ifdef HYDRA_GM_NO_ROUND_SYNC
+#define GM_ROUND_SYNC() do {} while (0)
+#else
+#define GM_ROUND_SYNC() __syncthreads()
+#endif
+#ifndef HYDRA_GM_FT
+#define HYDRA_GM_FT 2
+#endif
+constexpr int GM_FT = HYDRA_GM_FT;
+constexpr int GM_WAVES = 11;
+constexpr int GM_THREADS = 64 * GM_WAVES;
+constexpr int GM_NV = 8;                      // vectors per pass
+constexpr int GM_MAX_RPW = 3;                 // up to 33 blocks = 528 antennas
+
+__host__ __device__ inline long long gm_blk(int A, int B, int nb) {      // A <= B
+  return (long long)A * nb - (long long)A * (A - 1) / 2 + (B - A);
+}
+// entry (a, b) of a 16 x 16 block: sixteen 4 x 4 sub-tiles of one 128-byte line each, so that the 16
+// lanes of a quarter-wave touch 4 lines whether they walk a row (b = 4 g + t) or a column of the block
+__host__ __device__ inline int gm_elem(int a, int b) {
+  return ((((a >> 2) << 2) + (b >> 2)) << 4) + ((a & 3) << 2) + (b & 3);
+}
+
+// One workgroup per (block, 4 consecutive chunks = 8 samples): thread (a, b) reads its pair's model
+// and noise weight for 8 consecutive samples (one 128-byte / 64-byte run each) and writes the
+// entry of the 4 chunks.  gains == NULL: model_vis already carries them.
+constexpr int GM_WB_GROUPS = 16;
+__global__ void __launch_bounds__(256)
+gain_weights_blocks_kernel(const f64x2* __restrict__ mv, const f64x2* __restrict__ gains,
+                           const double* __restrict__ w, const int32_t* __restrict__ pairb, int nant,
+                           int nft, int nb, double* __restrict__ Wb) {
+  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+  int A = 0, B;
+  {
+    int base = 0;
+    const int blk = blockIdx.x;
+    while (A + 1 < nb && base + (nb - A) <= blk) { base += nb - A; ++A; }
+    B = A + (blk - base);
+  }
+  const long long nblk = (long long)nb * (nb + 1) / 2;
+  const int ag = 16 * A + a, bg = 16 * B + b;
+  int pair = -1;
+  if (ag < nant && bg < nant && ag != bg) pair = pairb[(size_t)ag * nant + bg];
+  // several groups of 8 samples per workgroup (one group each made 118 000 workgroups of a few
+  // hundred cycles at config 4: 8.3 ms, bound by their dispatch)
+  for (int grp = blockIdx.y * GM_WB_GROUPS; grp < min((blockIdx.y + 1) * GM_WB_GROUPS, (nft + 7) / 8); ++grp) {
+    const int ft0 = grp * 8;
+    double val[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int ft = min(ft0 + u, nft - 1);
+      double v = 0.0;
+      if (pair >= 0) {
+        const f64x2 m = mv[(size_t)pair * nft + ft];
+        v = (m.x * m.x + m.y * m.y) * (w ? w[(size_t)pair * nft + ft] : 1.0);
+        if (gains) {
+          const f64x2 ga = gains[(size_t)ag * nft + ft], gb = gains[(size_t)bg * nft + ft];
+          v *= (ga.x * ga.x + ga.y * ga.y) * (gb.x * gb.x + gb.y * gb.y);
+        }
+      }
+      val[u] = (ft0 + u < nft) ? v : 0.0;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const long long chunk = (ft0 + u) / GM_FT;
+      const int f = (ft0 + u) % GM_FT;
+      if ((long long)chunk * GM_FT >= nft) break;
+      Wb[((chunk * nblk + blockIdx.x) * GM_FT + f) * 256 + gm_elem(a, b)] = val[u];
+    }
+  }
+}
+
+// BLK: the fields come and go in SAMPLE-MAJOR layout Gc / Yc [ft][16 nb antennas][16 columns] (one
+// pass of 8 vectors; Gc already conjugated, rows >= Nant and columns >= 2 nvec zero) as
+// gain_basis_fwd_blocks_kernel writes and gain_basis_adj_blocks_kernel reads it: a workgroup's
+// fields are then one contiguous 84 KiB piece and a lane group's 16 columns one 128-byte line,
+// where the (nvec, Nant, Nft) arrays of the other kernels hand a workgroup 32-byte pieces of 2648
+// lines.
+template <int RPW, bool BLK>
+__global__ void __launch_bounds__(GM_THREADS)
+gain_pairs_mfma_kernel(const f64x2* __restrict__ g, const double* __restrict__ Wb,
+                       const double* __restrict__ sw, int nant, int nft, int nb, int v0, int nvec,
+                       int nchunk, f64x2* __restrict__ y) {
+  extern __shared__ __align__(16) unsigned char smem[];
+  double* s_g = reinterpret_cast<double*>(smem);             // [GM_FT][16 nb][16]
+  const int nap = 16 * nb;
+  double* s_sw = s_g + (size_t)GM_FT * nap * 16;             // [GM_FT][16 nb]
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int lr = lane & 15, gq = lane >> 4;
+  // consecutive workgroup ids go round robin to the 8 XCDs: give every XCD a contiguous run of
+  // chunks, so that the 4 chunks that share a 128-byte line of g / y meet in one L2
+  const int per_x = (nchunk + 7) / 8;
+  const int chunk = (blockIdx.x & 7) * per_x + (blockIdx.x >> 3);
+  if (chunk >= nchunk) return;
+  const int ft0 = chunk * GM_FT;
+  const long long nblk = (long long)nb * (nb + 1) / 2;
+  const double* wchunk = Wb + (long long)chunk * nblk * GM_FT * 256;
+
+  if (BLK) {
+    // one contiguous piece: samples ft0 .. ft0 + GM_FT - 1 (the array is padded to whole chunks)
+    const f64x2* src = g + (size_t)ft0 * nap * 8;
+    f64x2* dst = reinterpret_cast<f64x2*>(s_g);
+    const int total = GM_FT * nap * 8;
+    for (int e0 = tid; e0 < total; e0 += 8 * GM_THREADS) {
+      f64x2 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) t[u] = src[min(e0 + u * GM_THREADS, total - 1)];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (e0 + u * GM_THREADS < total) dst[e0 + u * GM_THREADS] = t[u];
+    }
+  } else {
+    // conj(g) of this chunk -> LDS; antennas >= nant, vectors >= nvec and samples >= nft are zero
+    for (int e = tid; e < GM_NV * nap; e += GM_THREADS) {
+      const int v = e / nap, a = e - v * nap;
+      f64x2 gv[GM_FT];
+#pragma unroll
+      for (int f = 0; f < GM_FT; ++f) {
+        const bool ok = a < nant && v0 + v < nvec && ft0 + f < nft;
+        gv[f] = ok ? g[((size_t)(v0 + v) * nant + a) * nft + ft0 + f] : f64x2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int f = 0; f < GM_FT; ++f) {
+        double* d = s_g + ((size_t)f * nap + a) * 16 + 2 * v;
+        d[0] = gv[f].x;
+        d[1] = -gv[f].y;
+      }
+    }
+  }
+  // the diagonal term's factors of this chunk
+  for (int e = tid; e < GM_FT * nap; e += GM_THREADS) {
+    const int f = e / nap, a = e - f * nap;
+    s_sw[e] = (sw && a < nant && ft0 + f < nft) ? sw[(size_t)a * nft + ft0 + f] : 0.0;
+  }
+
+  // Both ways of taking a block are TWO 16-byte loads per lane and sample, no branch around them
+  // (a branch with a different number of loads on either side ended in vmcnt(0) before every
+  // batch, and with four 8-byte loads per sample the kernel was bound by the number of vector-memory
+  // instructions: 0.53 ms for the loads alone).  As stored, lane (a = lr, g) takes its row of
+  // sub-tile (lr / 4, g) -- 32 contiguous bytes.  Transposed, lane (b = lr, g) needs column lr % 4
+  // of sub-tile (g, lr / 4): the even lane of a pair loads rows 0, 1 and the odd lane rows 2, 3 of the
+  // pair's two columns, and each hands the other its half (two DPP moves per double).
+  struct Raw {
+    f64x2 v[RPW][GM_FT][2];
+  };
+  auto load_round = [&](Raw& o, int s) {
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int X = min(wave + GM_WAVES * k, nb - 1);       // (rows past the end repeat the last)
+      int P = s - X;
+      if (P < 0) P += nb;
+      const bool direct = X <= P;
+      const int off = direct ? gm_elem(lr, 4 * gq)
+                             : ((((gq << 2) + (lr >> 2)) << 4) + ((lr & 1) << 3) + (lr & 2));
+      const double* base = wchunk + gm_blk(min(X, P), max(X, P), nb) * GM_FT * 256 + off;
+      const int second = direct ? 2 : 4;                      // next pair of the row / next row
+#pragma unroll
+      for (int f = 0; f < GM_FT; ++f) {
+#ifdef HYDRA_GM_NO_LOAD
+        o.v[k][f][0] = f64x2{(double)off, 1.0};
+        o.v[k][f][1] = f64x2{(double)second, 2.0};
+#elif defined(HYDRA_GM_ONE_READER)
+        if (direct) {
+          o.v[k][f][0] = *reinterpret_cast<const f64x2*>(base + f * 256);
+          o.v[k][f][1] = *reinterpret_cast<const f64x2*>(base + f * 256 + second);
+        } else {
+          o.v[k][f][0] = f64x2{(double)off, 1.0};
+          o.v[k][f][1] = f64x2{(double)second, 2.0};
+        }
+#else
+        o.v[k][f][0] = *reinterpret_cast<const f64x2*>(base + f * 256);
+        o.v[k][f][1] = *reinterpret_cast<const f64x2*>(base + f * 256 + second);
+#endif
+      }
+    }
+  };
+  auto swap_pair = [&](double x) {          // the value of lane ^ 1 (quad permutation 1,0,3,2)
+    int lo = __builtin_amdgcn_update_dpp(0, __double2loint(x), 0xB1, 0xF, 0xF, true);
+    int hi = __builtin_amdgcn_update_dpp(0, __double2hiint(x), 0xB1, 0xF, 0xF, true);
+    return __hiloint2double(hi, lo);
+  };
+  // the four k-step operands of (row k, sample f) from the raw loads of round s
+  auto operands = [&](const Raw& o, int s, int k, int f, double (&w)[4]) {
+    const int X = min(wave + GM_WAVES * k, nb - 1);
+    int P = s - X;
+    if (P < 0) P += nb;
+    const f64x2 v0 = o.v[k][f][0], v1 = o.v[k][f][1];
+    if (X <= P) {                                            // wave-uniform
+      w[0] = v0.x; w[1] = v0.y; w[2] = v1.x; w[3] = v1.y;
+    } else {
+      const bool odd = lr & 1;
+      const double r0 = swap_pair(odd ? v0.x : v0.y), r1 = swap_pair(odd ? v1.x : v1.y);
+      w[0] = odd ? r0 : v0.x;
+      w[1] = odd ? r1 : v1.x;
+      w[2] = odd ? v0.y : r0;
+      w[3] = odd ? v1.y : r1;
+    }
+  };
+
+  f64x4 acc[RPW][GM_FT];
+#pragma unroll
+  for (int k = 0; k < RPW; ++k)
+#pragma unroll
+    for (int f = 0; f < GM_FT; ++f) acc[k][f] = f64x4{0.0, 0.0, 0.0, 0.0};
+  auto multiply = [&](const Raw& o, int s) {
+#pragma unroll
+    for (int k = 0; k < RPW; ++k) {
+      const int X = wave + GM_WAVES * k;
+      if (X >= nb) continue;
+      int P = s - X;
+      if (P < 0) P += nb;
+      const double* gp = s_g + ((size_t)16 * P + 4 * gq) * 16 + lr;
+      double w[GM_FT][4];
+#pragma unroll
+      for (int f = 0; f < GM_FT; ++f) operands(o, s, k, f, w[f]);
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int f = 0; f < GM_FT; ++f)
+#ifdef HYDRA_GM_NO_MFMA
+          acc[k][f][0] += w[f][t];
+#else
+          acc[k][f] = __builtin_amdgcn_mfma_f64_16x16x4f64(w[f][t], gp[((size_t)f * nap + t) * 16],
+                                                           acc[k][f], 0, 0, 0);
+#endif
+    }
+  };
+  // The fragments of a round are fetched two rounds ahead of their use into three register sets
+  // that take turns (a copy from one set to the next would wait for the newest loads: the loop is
+  // unrolled by three instead); with three rows per wave three sets do not fit beside the
+  // accumulators: two sets, one round ahead.
+  Raw fa, fb, fc;
+  auto at = [&](int s) { return min(s, nb - 1); };
+  load_round(fa, 0);
+  if (RPW <= 2) {
+    load_round(fb, at(1));
+    __syncthreads();                                 // the fields are in place
+    for (int s = 0; s < nb; s += 3) {
+      load_round(fc, at(s + 2));
+      multiply(fa, s);
+      GM_ROUND_SYNC();                               // the two readers of a block stay in step
+      load_round(fa, at(s + 3));
+      if (s + 1 < nb) multiply(fb, s + 1);
+      GM_ROUND_SYNC();
+      load_round(fb, at(s + 4));
+      if (s + 2 < nb) multiply(fc, s + 2);
+      GM_ROUND_SYNC();
+    }
+  } else {
+    __syncthreads();
+    for (int s = 0; s < nb; s += 2) {
+      load_round(fb, at(s + 1));
+      multiply(fa, s);
+      __syncthreads();
+      load_round(fa, at(s + 2));
+      if (s + 1 < nb) multiply(fb, s + 1);
+      __syncthreads();
+    }
+  }
+
+  // y[v][a][ft] = g sw + conj(T): lane (j = lr, gq) holds rows a = 16 X + gq + 4 e
+  const int v = lr >> 1, ri = lr & 1;
+  double* yd = reinterpret_cast<double*>(y);
+#pragma unroll
+  for (int k = 0; k < RPW; ++k) {
+    const int X = wave + GM_WAVES * k;
+    if (X >= nb) continue;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      const int a = 16 * X + gq + 4 * e;
+      if (a >= nant) continue;
+#pragma unroll
+      for (int f = 0; f < GM_FT; ++f) {
+        if (ft0 + f >= nft) continue;
+        const double gc = s_g[((size_t)f * nap + a) * 16 + lr];          // re, or -im
+        const double val = (ri ? -gc : gc) * s_sw[f * nap + a] + acc[k][f][e];
+        if (BLK) yd[((size_t)(ft0 + f) * nap + a) * 16 + lr] = val;
+        else if (v0 + v < nvec) yd[(((size_t)(v0 + v) * nant + a) * nft + ft0 + f) * 2 + ri] = val;
+      }
+    }
+  }
+}
+
+// Gc[ft][a][2 v], [2 v + 1] = Re, -Im of sum_m F[m,ft] s_m (xre[v0+v,a,m] + i xim[v0+v,a,m]) for the
+// 8 vectors of a pass, sample-major (rows a >= Nant, vectors >= nvec and the samples that pad the
+// last chunk are written as zeros).  A wave owns one antenna and 64 samples: the basis values a
+// lane loads serve the 8 vectors, whose scaled amplitudes are LDS broadcasts.
+__global__ void __launch_bounds__(256)
+gain_basis_fwd_blocks_kernel(const double* __restrict__ x, const f64x2* __restrict__ F,
+                             const double* __restrict__ s, int nant, int nmodes, int nft, int nap,
+                             int nftp, int v0, int nvec, f64x2* __restrict__ Gc) {
+  __shared__ f64x2 s_z[4][GM_NV][GF_MC];
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int ft = blockIdx.x * 64 + lane, ftc = min(ft, nft - 1);
+  const int a = blockIdx.y * 4 + wave;
+  f64x2 acc[GM_NV];
+#pragma unroll
+  for (int v = 0; v < GM_NV; ++v) acc[v] = f64x2{0.0, 0.0};
+  for (int m0 = 0; m0 < nmodes; m0 += GF_MC) {
+    f64x2 fv[GF_MC];
+#pragma unroll
+    for (int u = 0; u < GF_MC; ++u) fv[u] = F[(size_t)min(m0 + u, nmodes - 1) * nft + ftc];
+    __syncthreads();
+    for (int e = threadIdx.x; e < 4 * GM_NV * GF_MC; e += 256) {
+      const int q = e / (GM_NV * GF_MC), v = (e / GF_MC) % GM_NV, u = e % GF_MC, m = m0 + u;
+      const int aa = blockIdx.y * 4 + q;
+      f64x2 z = {0.0, 0.0};
+      if (m < nmodes && aa < nant && v0 + v < nvec) {
+        const double* xre = x + (size_t)(v0 + v) * 2 * nant * nmodes;
+        const size_t o = (size_t)aa * nmodes + m;
+        const double sm = s ? s[m] : 1.0;
+        z = f64x2{sm * xre[o], sm * xre[o + (size_t)nant * nmodes]};
+      }
+      s_z[q][v][u] = z;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int u = 0; u < GF_MC; ++u)
+#pragma unroll
+      for (int v = 0; v < GM_NV; ++v) {
+        const f64x2 z = s_z[wave][v][u];
+        acc[v].x = __builtin_fma(fv[u].x, z.x, acc[v].x);
+        acc[v].x = __builtin_fma(-fv[u].y, z.y, acc[v].x);
+        acc[v].y = __builtin_fma(fv[u].x, z.y, acc[v].y);
+        acc[v].y = __builtin_fma(fv[u].y, z.x, acc[v].y);
+      }
+  }
+  if (ft < nftp && a < nap) {
+    f64x2* row = Gc + ((size_t)ft * nap + a) * 8;
+    const bool live = ft < nft;
+#pragma unroll
+    for (int v = 0; v < GM_NV; ++v) row[v] = live ? f64x2{acc[v].x, -acc[v].y} : f64x2{0.0, 0.0};
+  }
+}
+
+// out[v0+v, a*nmodes+m] = Re, out[v0+v, nant*nmodes + a*nmodes+m] = Im of
+//   s_m sum_ft conj(F[m,ft]) y[v,a,ft]  (+ add) with y in the sample-major layout Yc[ft][a][16].
+// One workgroup of 16 waves per antenna: wave (half q, mode group mg) sums the samples
+// 64 (q + 2 i) + lane for the modes 2 mg, 2 mg + 1 of all 8 vectors (a 128-byte row of Yc per
+// sample), the lanes' sums are added through LDS as in gain_basis_adj_kernel and the two halves
+// in order: fixed summation order.
+constexpr int GAB_MODES = 2, GAB_Q = 2, GAB_MG = 16 / GAB_Q;
+__global__ void __launch_bounds__(1024)
+gain_basis_adj_blocks_kernel(const f64x2* __restrict__ Yc, const f64x2* __restrict__ F,
+                             const double* __restrict__ s, const double* __restrict__ add, int nant,
+                             int nmodes, int nft, int nap, int v0, int nvec,
+                             double* __restrict__ out) {
+  __shared__ double s_tr[16][64][9];
+  __shared__ double s_part[16][GAB_MODES * GM_NV * 2];
+  const int a = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int q = wave / GAB_MG, mg = wave % GAB_MG;
+  for (int m0 = 0; m0 < nmodes; m0 += GAB_MG * GAB_MODES) {
+    const int mb = m0 + GAB_MODES * mg;
+    f64x2 acc[GAB_MODES][GM_NV];
+#pragma unroll
+    for (int mm = 0; mm < GAB_MODES; ++mm)
+#pragma unroll
+      for (int v = 0; v < GM_NV; ++v) acc[mm][v] = f64x2{0.0, 0.0};
+    for (int base = q * 64; base < nft; base += GAB_Q * 64) {
+      const int ft = base + lane, ftc = min(ft, nft - 1);
+      const f64x2* row = Yc + ((size_t)ftc * nap + a) * 8;
+      f64x2 yv[GM_NV], fv[GAB_MODES];
+#pragma unroll
+      for (int v = 0; v < GM_NV; ++v) yv[v] = row[v];
+#pragma unroll
+      for (int mm = 0; mm < GAB_MODES; ++mm) fv[mm] = F[(size_t)min(mb + mm, nmodes - 1) * nft + ftc];
+      if (ft >= nft) {
+#pragma unroll
+        for (int v = 0; v < GM_NV; ++v) yv[v] = f64x2{0.0, 0.0};
+      }
+#pragma unroll
+      for (int mm = 0; mm < GAB_MODES; ++mm)
+#pragma unroll
+        for (int v = 0; v < GM_NV; ++v) {    // conj(f) y, four FMAs
+          acc[mm][v].x = __builtin_fma(fv[mm].x, yv[v].x, acc[mm][v].x);
+          acc[mm][v].x = __builtin_fma(fv[mm].y, yv[v].y, acc[mm][v].x);
+          acc[mm][v].y = __builtin_fma(fv[mm].x, yv[v].y, acc[mm][v].y);
+          acc[mm][v].y = __builtin_fma(-fv[mm].y, yv[v].x, acc[mm][v].y);
+        }
+    }
+    // lanes -> one sum per wave, 8 values at a time
+#pragma unroll
+    for (int b0 = 0; b0 < GAB_MODES * GM_NV * 2; b0 += 8) {
+      __syncthreads();
+#pragma unroll
+      for (int i = 0; i < 8; ++i) {
+        const int idx = b0 + i;                        // (mm, v, re/im)
+        const f64x2 c = acc[idx / (2 * GM_NV)][(idx / 2) % GM_NV];
+        s_tr[wave][lane][i] = (idx & 1) ? c.y : c.x;
+      }
+      __syncthreads();
+      const int i = lane & 7, grp = lane >> 3;
+      double t = 0.0;
+#pragma unroll
+      for (int r = 0; r < 8; ++r) t += s_tr[wave][grp * 8 + r][i];
+      t += __shfl_xor(t, 8, 64);
+      t += __shfl_xor(t, 16, 64);
+      t += __shfl_xor(t, 32, 64);
+      if (lane < 8) s_part[wave][b0 + lane] = t;
+    }
+    __syncthreads();
+    // halves -> out: thread (mg, mm, v)
+    if (tid < GAB_MG * GAB_MODES * GM_NV) {
+      const int g4 = tid / (GAB_MODES * GM_NV), mm = (tid / GM_NV) % GAB_MODES, v = tid % GM_NV;
+      const int m = m0 + GAB_MODES * g4 + mm;
+      if (m < nmodes && v0 + v < nvec) {
+        double re = 0.0, im = 0.0;
+#pragma unroll
+        for (int qq = 0; qq < GAB_Q; ++qq) {
+          re += s_part[qq * GAB_MG + g4][(mm * GM_NV + v) * 2];
+          im += s_part[qq * GAB_MG + g4][(mm * GM_NV + v) * 2 + 1];
+        }
+        const double sm = s ? s[m] : 1.0;
+        const size_t o = (size_t)(v0 + v) * 2 * nant * nmodes + (size_t)a * nmodes + m;
+        const size_t oi = o + (size_t)nant * nmodes;
+        out[o] = sm * re + (add ? add[o] : 0.0);
+        out[oi] = sm * im + (add ? add[oi] : 0.0);
+      }
+    }
+    __syncthreads();
+  }
+}
+
+
+// Ft[ft][n], n < nmp: Re F[n][ft], nmp <= n < 2 nmp: Im F[n - nmp][ft] (zero for modes >= nmodes and
+// samples >= nft): the basis as the B operand of the real product below, a 128-byte line per
+// 16 columns.  1 MB at config 4, rebuilt per call.
+__global__ void __launch_bounds__(256)
+gain_basis_table_kernel(const f64x2* __restrict__ F, int nmodes, int nft, int nmp, int nftp,
+                        double* __restrict__ Ft) {
+  const size_t total = (size_t)nftp * 2 * nmp;
+  for (size_t e = blockIdx.x * (size_t)blockDim.x + threadIdx.x; e < total;
+       e += (size_t)gridDim.x * blockDim.x) {
+    const int ft = (int)(e / (2 * nmp)), n = (int)(e % (2 * nmp));
+    const int m = n < nmp ? n : n - nmp;
+    double v = 0.0;
+    if (m < nmodes && ft < nft) {
+      const f64x2 f = F[(size_t)m * nft + ft];
+      v = n < nmp ? f.x : f.y;
+    }
+    Ft[e] = v;
+  }
+}
+
+// The adjoint basis transform of a pass of 8 vectors as ONE real product per antenna on the matrix
+// cores: D[j][n] = sum_ft Yc[ft][a][j] Ft[ft][n] (16 x 2 nmp, K = Nft), then
+//   Re out[v][m] = D[2v][m] + D[2v+1][nmp + m],  Im out[v][m] = D[2v+1][m] - D[2v][nmp + m]
+// (conj(F) y summed over the samples).  Both operands are 128-byte lines straight from global
+// memory (A: the antenna's row of Yc for each of the 4 samples of a k-step; B: rows of Ft).  A
+// workgroup of 8 waves per antenna, wave w the k-steps w, w + 8, ...; the waves' sums are added
+// through LDS in wave order.  NCB = 2 nmp / 16 column blocks (<= 4: up to 32 modes).
+template <int NCB>
+__global__ void __launch_bounds__(512)
+gain_basis_adj_mfma_kernel(const double* __restrict__ Yc, const double* __restrict__ Ft,
+                           const double* __restrict__ s, const double* __restrict__ add, int nant,
+                           int nmodes, int nft, int nap, int v0, int nvec,
+                           double* __restrict__ out) {
+  __shared__ double s_d[8][NCB][256];
+  constexpr int nmp = 8 * NCB;
+  const int a = blockIdx.x;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int lr = lane & 15, gq = lane >> 4;
+  f64x4 acc[NCB];
+#pragma unroll
+  for (int c = 0; c < NCB; ++c) acc[c] = f64x4{0.0, 0.0, 0.0, 0.0};
+  const int nks = (nft + 3) / 4;
+  constexpr int UN = 4;
+  for (int k0 = wave; k0 < nks; k0 += 8 * UN) {
+    double av[UN], bv[UN][NCB];
+#pragma unroll
+    for (int u = 0; u < UN; ++u) {
+      const int ft = 4 * (k0 + 8 * u) + gq, ftc = min(ft, nft - 1);
+      av[u] = Yc[((size_t)ftc * nap + a) * 16 + lr];
+      if (ft >= nft) av[u] = 0.0;
+#pragma unroll
+      for (int c = 0; c < NCB; ++c) bv[u][c] = Ft[(size_t)ftc * (2 * nmp) + 16 * c + lr];
+    }
+#pragma unroll
+    for (int u = 0; u < UN; ++u)
+#pragma unroll
+      for (int c = 0; c < NCB; ++c)
+        acc[c] = __builtin_amdgcn_mfma_f64_16x16x4f64(av[u], bv[u][c], acc[c], 0, 0, 0);
+  }
+#pragma unroll
+  for (int c = 0; c < NCB; ++c)
+#pragma unroll
+    for (int e = 0; e < 4; ++e) s_d[wave][c][(gq + 4 * e) * 16 + lr] = acc[c][e];   // [j][n local]
+  __syncthreads();
+  // thread (v, m): the eight waves in order, then the complex combination
+  for (int e = tid; e < GM_NV * nmp; e += 512) {
+    const int v = e / nmp, m = e % nmp;
+    if (m >= nmodes || v0 + v >= nvec) continue;
+    auto D = [&](int j, int n) {
+      double t = 0.0;
+#pragma unroll
+      for (int w = 0; w < 8; ++w) t += s_d[w][n >> 4][j * 16 + (n & 15)];
+      return t;
+    };
+    const double re = D(2 * v, m) + D(2 * v + 1, nmp + m);
+    const double im = D(2 * v + 1, m) - D(2 * v, nmp + m);
+    const double sm = s ? s[m] : 1.0;
+    const size_t o = (size_t)(v0 + v) * 2 * nant * nmodes + (size_t)a * nmodes + m;
+    const size_t oi = o + (size_t)nant * nmodes;
+    out[o] = sm * re + (add ? add[o] : 0.0);
+    out[oi] = sm * im + (add ? add[oi] : 0.0);
+  }
+}
+
 }  // namespace hydra
 
 using namespace hydra;
@@ -822,6 +1354,32 @@ static int check_adj(const char* name, const int32_t* adj_ptr_host, int nant, in
                     name);
   return HYDRA_OK;
 }
+
+template <bool BLK>
+static int launch_pairs_mfma(const double* g, int nvec, int nant, int nft, const double* Wb,
+                             const double* sw, double* y, int v0, hipStream_t st) {
+  const int nb = (nant + 15) / 16;
+  const int rpw = (nb + GM_WAVES - 1) / GM_WAVES;
+  const int nchunk = (nft + GM_FT - 1) / GM_FT;
+  const size_t lds = (size_t)GM_FT * 16 * nb * (16 + 1) * 8;
+  const unsigned grid = (unsigned)((nchunk + 7) / 8 * 8);
+  const f64x2* gp = reinterpret_cast<const f64x2*>(g);
+  f64x2* yp = reinterpret_cast<f64x2*>(y);
+#define HYDRA_GM_LAUNCH(R)                                                                        \
+  do {                                                                                            \
+    if (int rc = reserve_lds(reinterpret_cast<const void*>(&gain_pairs_mfma_kernel<R, BLK>), lds))  \
+      return rc;                                                                                  \
+    gain_pairs_mfma_kernel<R, BLK><<<grid, GM_THREADS, lds, st>>>(gp, Wb, sw, nant, nft, nb, v0,     \
+                                                                  nvec, nchunk, yp);               \
+  } while (0)
+  if (rpw == 1) HYDRA_GM_LAUNCH(1);
+  else if (rpw == 2) HYDRA_GM_LAUNCH(2);
+  else HYDRA_GM_LAUNCH(3);
+#undef HYDRA_GM_LAUNCH
+  HYDRA_CHECK_LAUNCH("hydra_gain_pairs_mfma");
+  return HYDRA_OK;
+}
+
 
 extern "C" {
 
@@ -992,6 +1550,96 @@ int hydra_gain_weights_stream(const double* model_vis, const double* inv_noise, 
   else if (ft == 4) gain_weights_stream_kernel<4><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
   else gain_weights_stream_kernel<2><<<grid, 256, 0, st>>>(mv, inv_noise, pairb, nant, nft, Wt);
   HYDRA_CHECK_LAUNCH("hydra_gain_weights_stream");
+  return HYDRA_OK;
+}
+
+size_t hydra_gain_blocks_weight_count(int nant, int nft) {
+  if (nant < 2 || nft <= 0) return 0;
+  const int nb = (nant + 15) / 16;
+  if (nb > GM_WAVES * GM_MAX_RPW || (size_t)GM_FT * 16 * nb * (16 + 1) * 8 > 160 * 1024) return 0;
+  const long long nchunk = (nft + GM_FT - 1) / GM_FT;
+  return (size_t)(nchunk * ((long long)nb * (nb + 1) / 2) * GM_FT * 256);
+}
+
+int hydra_gain_weights_blocks(const double* model_vis, const double* gains, const double* inv_noise,
+                              int nbl, int nant, int nft, const int32_t* pairb, double* Wb,
+                              void* stream) {
+  HYDRA_CHECK_ARG(model_vis && pairb && Wb && nbl > 0 && nant >= 2 && nft > 0,
+                  "hydra_gain_weights_blocks: bad arguments");
+  HYDRA_CHECK_ARG(hydra_gain_blocks_weight_count(nant, nft) != 0,
+                  "hydra_gain_weights_blocks: %d antennas do not fit the block layout", nant);
+  const int nb = (nant + 15) / 16;
+  const int ngroups = ((nft + 7) / 8 + GM_WB_GROUPS - 1) / GM_WB_GROUPS;
+  HYDRA_CHECK_ARG(ngroups <= 65535, "hydra_gain_weights_blocks: nft too large");
+  dim3 grid(nb * (nb + 1) / 2, ngroups);
+  gain_weights_blocks_kernel<<<grid, 256, 0, as_stream(stream)>>>(
+      reinterpret_cast<const f64x2*>(model_vis), reinterpret_cast<const f64x2*>(gains), inv_noise,
+      pairb, nant, nft, nb, Wb);
+  HYDRA_CHECK_LAUNCH("hydra_gain_weights_blocks");
+  return HYDRA_OK;
+}
+
+int hydra_gain_pairs_mfma(const double* g, int nvec, int nant, int nft, const double* Wb,
+                          const double* sw, double* y, void* stream) {
+  HYDRA_CHECK_ARG(g && Wb && y && nvec > 0 && nant >= 2 && nft > 0,
+                  "hydra_gain_pairs_mfma: bad arguments");
+  HYDRA_CHECK_ARG(hydra_gain_blocks_weight_count(nant, nft) != 0,
+                  "hydra_gain_pairs_mfma: %d antennas do not fit the block layout", nant);
+  for (int v0 = 0; v0 < nvec; v0 += GM_NV)
+    if (int rc = launch_pairs_mfma<false>(g, nvec, nant, nft, Wb, sw, y, v0, as_stream(stream))) return rc;
+  return HYDRA_OK;
+}
+
+size_t hydra_gain_operator_blocks_workspace_bytes(int nant, int nft) {
+  if (hydra_gain_blocks_weight_count(nant, nft) == 0) return 0;
+  const size_t nap = (size_t)(nant + 15) / 16 * 16;
+  const size_t nftp = (size_t)(nft + GM_FT - 1) / GM_FT * GM_FT;
+  return 2 * nftp * nap * 16 * sizeof(double) +           // Gc and Yc of one pass of 8 vectors
+         nftp * 2 * 32 * sizeof(double);                  // the basis as a real (Nft, 2 x <= 32) table
+}
+
+int hydra_gain_operator_blocks(const double* x, int nvec, int nant, int nmodes, int nft,
+                               const double* Fbasis, const double* pspec_sqrt, const double* Wb,
+                               const double* sw, const double* add, double* out, void* workspace,
+                               size_t workspace_bytes, void* stream) {
+  HYDRA_CHECK_ARG(x && Fbasis && Wb && out && nvec > 0 && nant >= 2 && nmodes > 0 && nft > 0,
+                  "hydra_gain_operator_blocks: bad arguments");
+  const size_t need = hydra_gain_operator_blocks_workspace_bytes(nant, nft);
+  HYDRA_CHECK_ARG(need != 0, "hydra_gain_operator_blocks: %d antennas do not fit the block layout", nant);
+  if (!workspace || workspace_bytes < need)
+    return fail(HYDRA_ERR_WORKSPACE, "hydra_gain_operator_blocks: workspace too small (%zu < %zu bytes)",
+                workspace_bytes, need);
+  const int nap = (nant + 15) / 16 * 16;
+  const int nftp = (nft + GM_FT - 1) / GM_FT * GM_FT;
+  double* Gc = static_cast<double*>(workspace);
+  double* Yc = Gc + (size_t)nftp * nap * 16;
+  double* Ft = Yc + (size_t)nftp * nap * 16;
+  hipStream_t st = as_stream(stream);
+  const f64x2* Fp = reinterpret_cast<const f64x2*>(Fbasis);
+  const int nmp = nmodes <= 8 ? 8 : (nmodes <= 16 ? 16 : (nmodes <= 24 ? 24 : 32));
+  if (nmodes <= 32) {
+    gain_basis_table_kernel<<<512, 256, 0, st>>>(Fp, nmodes, nft, nmp, nftp, Ft);
+    HYDRA_CHECK_LAUNCH("hydra_gain_operator_blocks(basis table)");
+  }
+  for (int v0 = 0; v0 < nvec; v0 += GM_NV) {
+    gain_basis_fwd_blocks_kernel<<<dim3((nftp + 63) / 64, nap / 4), 256, 0, st>>>(
+        x, Fp, pspec_sqrt, nant, nmodes, nft, nap, nftp, v0, nvec, reinterpret_cast<f64x2*>(Gc));
+    HYDRA_CHECK_LAUNCH("hydra_gain_operator_blocks(basis)");
+    if (int rc = launch_pairs_mfma<true>(Gc, nvec, nant, nft, Wb, sw, Yc, v0, st)) return rc;
+    if (nmodes <= 8)
+      gain_basis_adj_mfma_kernel<1><<<nant, 512, 0, st>>>(Yc, Ft, pspec_sqrt, add, nant, nmodes, nft, nap, v0, nvec, out);
+    else if (nmodes <= 16)
+      gain_basis_adj_mfma_kernel<2><<<nant, 512, 0, st>>>(Yc, Ft, pspec_sqrt, add, nant, nmodes, nft, nap, v0, nvec, out);
+    else if (nmodes <= 24)
+      gain_basis_adj_mfma_kernel<3><<<nant, 512, 0, st>>>(Yc, Ft, pspec_sqrt, add, nant, nmodes, nft, nap, v0, nvec, out);
+    else if (nmodes <= 32)
+      gain_basis_adj_mfma_kernel<4><<<nant, 512, 0, st>>>(Yc, Ft, pspec_sqrt, add, nant, nmodes, nft, nap, v0, nvec, out);
+    else
+      gain_basis_adj_blocks_kernel<<<nant, 1024, 0, st>>>(reinterpret_cast<const f64x2*>(Yc), Fp,
+                                                          pspec_sqrt, add, nant, nmodes, nft, nap, v0,
+                                                          nvec, out);
+    HYDRA_CHECK_LAUNCH("hydra_gain_operator_blocks(adjoint basis)");
+  }
   return HYDRA_OK;
 }
 

@@ -175,6 +175,8 @@ class GainOperator:
         self.s = _dev.f64(pspec_sqrt)
         assert tuple(self.s.shape) == (self.nmodes,)
         self._mv, self._w, self._W = mv, w, None
+        #: batches of vectors go through the matrix-core pair kernel when the pair list allows
+        self.batch_mfma = True
         self.n = 2 * self.idx.nants * self.nmodes
         #: use the LDS-tiled pair kernel when the pair list has no duplicates
         self.tiled = True
@@ -207,6 +209,7 @@ class GainOperator:
         self.nft = int(np.prod(F.shape[1:]))
         self.nbl = int(w.shape[0])
         self._mv, self._w, self._W, self._model = None, w, None, model
+        self.batch_mfma = True
         self.n = 2 * idx.nants * self.nmodes
         self.tiled, self.stream = True, True
         self.Wt, self.sw = Wt, sw
@@ -227,6 +230,35 @@ class GainOperator:
                       self.nbl * self.nft, _dev.ptr(self._W), _dev.stream_ptr())
         return self._W
 
+    @property
+    def Wb(self):
+        """The fused weights in the 16 x 16 antenna-block layout of the matrix-core batch kernel
+        (csrc/gain.hip, gain_pairs_mfma_kernel), or None if the pair list has duplicates /
+        auto-correlations or the array does not fit; built on first use (with ``sw``, the sum of
+        the weights over each antenna's pairs, if the streamed form has not left it)."""
+        if getattr(self, "_Wb", None) is None:
+            self._Wb = False
+            nants = self.idx.nants
+            count = _dev._lib.query("hydra_gain_blocks_weight_count", nants, self.nft)
+            if (self.idx.pair_table is not None and count > 0
+                    and not np.any(self.idx.i1 == self.idx.i2)):
+                st = _dev.stream_ptr()
+                Wb = _dev.empty((count,), torch.float64)
+                if self._mv is not None:
+                    mv, gg = self._mv, None
+                else:
+                    mv, gg = (_dev.c128(t) for t in self._model)
+                _dev.call("hydra_gain_weights_blocks", _dev.ptr(mv), _dev.ptr(gg), _dev.ptr(self._w),
+                          self.nbl, nants, self.nft, _dev.ptr(self.idx.pair_dev()), _dev.ptr(Wb), st)
+                if self.sw is None:
+                    ones = torch.ones((1, nants, self.nft), dtype=torch.complex128, device=Wb.device)
+                    y1 = _dev.empty((1, nants, self.nft), torch.complex128)
+                    _dev.call("hydra_gain_pairs_mfma", _dev.ptr(ones), 1, nants, self.nft,
+                              _dev.ptr(Wb), _dev.ptr(None), _dev.ptr(y1), st)
+                    self.sw = y1[0].real.contiguous()
+                self._Wb = Wb
+        return self._Wb if self._Wb is not False else None
+
     def local(self, X, add=None):
         X = _dev.f64(X)
         single = X.dim() == 1
@@ -236,6 +268,18 @@ class GainOperator:
         nants, nft = self.idx.nants, self.nft
         _, _, adj_ptr, adj_b, adj_o, _ = self.idx.dev()
         st = _dev.stream_ptr()
+        addb = None if add is None else _dev.f64(add).reshape(nvec, self.n)
+        if nvec > 1 and self.batch_mfma and self.Wb is not None:
+            # a batch: per sample the pair sums are a symmetric matrix times 2 nvec real columns --
+            # on the FP64 matrix cores, every weight read once per 8 vectors, the fields of a pass
+            # in a sample-major layout between the three kernels (csrc/gain.hip)
+            out = _dev.empty((nvec, self.n), torch.float64)
+            ws = _dev.workspace(_dev._lib.query("hydra_gain_operator_blocks_workspace_bytes", nants,
+                                                nft))
+            _dev.call("hydra_gain_operator_blocks", _dev.ptr(Xb), nvec, nants, self.nmodes, nft,
+                      _dev.ptr(self.F), _dev.ptr(self.s), _dev.ptr(self.Wb), _dev.ptr(self.sw),
+                      _dev.ptr(addb), _dev.ptr(out), _dev.ptr(ws), ws.numel(), st)
+            return out
         g = _dev.empty((nvec, nants, nft), torch.complex128)
         _dev.call("hydra_gain_basis_fwd", _dev.ptr(Xb), nvec, nants, self.nmodes, nft,
                   _dev.ptr(self.F), _dev.ptr(self.s), _dev.ptr(g), st)
@@ -252,7 +296,6 @@ class GainOperator:
                       self.nbl, _dev.host_ptr(self.idx.adj_ptr), _dev.ptr(adj_ptr),
                       _dev.ptr(adj_b), _dev.ptr(adj_o), int(self.idx.adj_b.size), _dev.ptr(y), st)
         out = _dev.empty((nvec, self.n), torch.float64)
-        addb = None if add is None else _dev.f64(add).reshape(nvec, self.n)
         _dev.call("hydra_gain_basis_adj", _dev.ptr(y), nvec, nants, self.nmodes, nft,
                   _dev.ptr(self.F), _dev.ptr(self.s), _dev.ptr(addb), _dev.ptr(out), st)
         return out[0] if single else out

@@ -487,6 +487,34 @@ int hydra_gain_weights_stream(const double* model_vis, const double* inv_noise, 
 int hydra_gain_pairs_stream(const double* g, int nant, int nft, const double* Wt, const double* sw,
                             double* y, void* stream);
 
+/* The same operator for a BATCH of fields on the FP64 matrix cores (BASELINE config 4, "batched CG
+ * matvecs"; gain_sampler.py:278-284 applied to several vectors at once): per (f,t) sample the pair
+ * sums are the real symmetric matrix W[{a,o}] times the 2 nvec real columns of the fields.
+ *   hydra_gain_blocks_weight_count : doubles of the block layout Wb (0: Nant does not fit)
+ *   hydra_gain_weights_blocks      : Wb <- |g_a conj(g_o) model_vis|^2 inv_noise in 16 x 16 antenna
+ *                                    blocks (gains NULL: model_vis carries them; inv_noise NULL: 1);
+ *                                    pairb as for hydra_gain_pairs_tiled, no duplicate pairs
+ *   hydra_gain_pairs_mfma          : y[v][a] = g[v][a] sw[a] + conj(sum_o W[{a,o}] g[v][o]) for
+ *                                    nvec fields g (nvec,Nant,Nft) c128, every weight read once per
+ *                                    8 vectors; sw (Nant,Nft) = sum of W over the pairs of an
+ *                                    antenna, or NULL for 0                                      */
+size_t hydra_gain_blocks_weight_count(int nant, int nft);
+int hydra_gain_weights_blocks(const double* model_vis, const double* gains, const double* inv_noise,
+                              int nbl, int nant, int nft, const int32_t* pairb, double* Wb,
+                              void* stream);
+int hydra_gain_pairs_mfma(const double* g, int nvec, int nant, int nft, const double* Wb,
+                          const double* sw, double* y, void* stream);
+/* The whole data term of the operator for a batch, out = S^1/2 F^H [pair sums] F S^1/2 x (+ add)
+ * (gain_sampler.py:256-301): hydra_gain_basis_fwd, hydra_gain_pairs_mfma and hydra_gain_basis_adj
+ * in one call with the fields of a pass of 8 vectors kept in a sample-major layout
+ * ([ft][antenna][2 x 8 real columns]) in the workspace, so that the pair kernel reads and writes
+ * whole lines.  x, add, out (nvec, 2 Nant Nmodes) f64 as for hydra_gain_basis_fwd / _adj.      */
+size_t hydra_gain_operator_blocks_workspace_bytes(int nant, int nft);
+int hydra_gain_operator_blocks(const double* x, int nvec, int nant, int nmodes, int nft,
+                               const double* Fbasis, const double* pspec_sqrt, const double* Wb,
+                               const double* sw, const double* add, double* out, void* workspace,
+                               size_t workspace_bytes, void* stream);
+
 /* Everything a gain GCR sample needs from the visibilities, in ONE pass over them -- the
  * driver's sequence example.py:690-745: ggv = apply_gains(model) (utils.py:63-110), resid = data -
  * ggv, the visibility half of construct_rhs_mpi (gain_sampler.py:201-213: z = resid N^-1 +

@@ -672,6 +672,100 @@ def test_streamed_gain_pairs_layouts(hy, nant, nft):
     assert _dev._lib.query("hydra_gain_stream_weight_count", 1800, nft) == 0
 
 
+@pytest.mark.parametrize("nant,nft,nvec", [(9, 3, 1), (40, 10, 8), (177, 7, 5), (331, 9, 8),
+                                           (360, 4, 11), (520, 2, 3)])
+def test_matrix_core_batch_pair_kernel_matches_adjacency_kernel(hy, nant, nft, nvec):
+    """hydra_gain_pairs_mfma (batch of fields: symmetric weight matrix of a sample x 2 nvec real
+    columns on the FP64 matrix cores, weights in 16 x 16 antenna blocks) against the adjacency
+    kernel and numpy on pair lists with holes (gain_sampler.py:278-284): 1, 2 and 3 block rows per
+    wave, odd sample counts (a half-filled chunk), fewer and more than 8 vectors; the weights from
+    a gain-applied model and from (model, gains)."""
+    import torch
+    from hydra_amd import _dev, gain_sampler as gs
+    rng = np.random.RandomState(nant)
+    pairs = [(i, j) for i in range(nant) for j in range(i + 1, nant)]
+    keep = rng.rand(len(pairs)) > 0.2
+    pairs = [p for p, k in zip(pairs, keep) if k]
+    nbl = len(pairs)
+    i1 = np.array([p[0] for p in pairs], dtype=np.int32)
+    i2 = np.array([p[1] for p in pairs], dtype=np.int32)
+    idx = gs._Index(i1, i2, nant)
+    dev = torch.device("cuda")
+    gen = torch.Generator(device=dev).manual_seed(nant)
+    mv = torch.randn((nbl, nft), dtype=torch.complex128, device=dev, generator=gen)
+    gains = torch.randn((nant, nft), dtype=torch.complex128, device=dev, generator=gen)
+    w = 1.0 + torch.rand((nbl, nft), dtype=torch.float64, device=dev, generator=gen)
+    g = torch.randn((nvec, nant, nft), dtype=torch.complex128, device=dev, generator=gen)
+    st = _dev.stream_ptr()
+    i1d, i2d = torch.as_tensor(i1, device=dev).long(), torch.as_tensor(i2, device=dev).long()
+    ggv = (gains[i1d] * gains[i2d].conj() * mv).contiguous()
+    W = _dev.empty((nbl, nft), torch.float64)
+    _dev.call("hydra_gain_weights", _dev.ptr(ggv), _dev.ptr(w), nbl * nft, _dev.ptr(W), st)
+    _, _, adj_ptr, adj_b, adj_o, _ = idx.dev()
+    y_c = _dev.empty((nvec, nant, nft), torch.complex128)
+    _dev.call("hydra_gain_pairs", _dev.ptr(g), nvec, nant, nft, _dev.ptr(W), nbl,
+              _dev.host_ptr(idx.adj_ptr), _dev.ptr(adj_ptr), _dev.ptr(adj_b), _dev.ptr(adj_o),
+              int(idx.adj_b.size), _dev.ptr(y_c), st)
+    count = _dev._lib.query("hydra_gain_blocks_weight_count", nant, nft)
+    assert count > 0
+    scale = float(y_c.abs().max())
+    for mvin, gin in ((ggv, None), (mv, gains)):
+        Wb = torch.full((count,), float("nan"), dtype=torch.float64, device=dev)
+        _dev.call("hydra_gain_weights_blocks", _dev.ptr(mvin), _dev.ptr(gin), _dev.ptr(w), nbl, nant,
+                  nft, _dev.ptr(idx.pair_dev()), _dev.ptr(Wb), st)
+        assert bool(torch.isfinite(Wb).all())             # every slot written
+        # every pair sits in exactly two slots of an off-diagonal... one slot, or two inside a
+        # diagonal block: the total is between once and twice the sum of the weights
+        tot, once = float(Wb.sum()), float(W.sum())
+        assert once * (1 - 1e-12) <= tot <= 2 * once * (1 + 1e-12)
+        ones = torch.ones((1, nant, nft), dtype=torch.complex128, device=dev)
+        y1 = _dev.empty((1, nant, nft), torch.complex128)
+        _dev.call("hydra_gain_pairs_mfma", _dev.ptr(ones), 1, nant, nft, _dev.ptr(Wb), _dev.ptr(None),
+                  _dev.ptr(y1), st)
+        sw = y1[0].real.contiguous()
+        sw_ref = torch.zeros((nant, nft), dtype=torch.float64, device=dev)
+        sw_ref.index_add_(0, i1d, W)
+        sw_ref.index_add_(0, i2d, W)
+        assert float((sw - sw_ref).abs().max()) <= 1e-12 * float(sw_ref.abs().max())
+        assert float(y1[0].imag.abs().max()) == 0.0
+        y_m = torch.full((nvec, nant, nft), float("nan"), dtype=torch.complex128, device=dev)
+        _dev.call("hydra_gain_pairs_mfma", _dev.ptr(g), nvec, nant, nft, _dev.ptr(Wb), _dev.ptr(sw),
+                  _dev.ptr(y_m), st)
+        assert float((y_m - y_c).abs().max()) <= 1e-12 * scale
+    # numpy on one sample: y_a = g_a sum_b W_b + conj(sum_b W_b g_other)
+    Wn, gn = W[:, 0].cpu().numpy(), g[0, :, 0].cpu().numpy()
+    T = np.zeros(nant, dtype=complex)
+    np.add.at(T, i1, Wn * gn[i2])
+    np.add.at(T, i2, Wn * gn[i1])
+    ref = gn * sw_ref[:, 0].cpu().numpy() + np.conj(T)
+    assert np.abs(y_m[0, :, 0].cpu().numpy() - ref).max() <= 1e-12 * np.abs(ref).max()
+    assert _dev._lib.query("hydra_gain_blocks_weight_count", 529, nft) == 0
+    # the whole data term in one call (fields sample-major between the three kernels) against
+    # basis transform -> adjacency pair kernel -> adjoint basis transform
+    for nmodes in (5, 16, 21, 40):
+        F = torch.randn((nmodes, nft), dtype=torch.complex128, device=dev, generator=gen)
+        ps = 0.5 + torch.rand(nmodes, dtype=torch.float64, device=dev, generator=gen)
+        n = 2 * nant * nmodes
+        X = torch.randn((nvec, n), dtype=torch.float64, device=dev, generator=gen)
+        add = torch.randn((nvec, n), dtype=torch.float64, device=dev, generator=gen)
+        gf = _dev.empty((nvec, nant, nft), torch.complex128)
+        _dev.call("hydra_gain_basis_fwd", _dev.ptr(X), nvec, nant, nmodes, nft, _dev.ptr(F), _dev.ptr(ps),
+                  _dev.ptr(gf), st)
+        yf = _dev.empty((nvec, nant, nft), torch.complex128)
+        _dev.call("hydra_gain_pairs", _dev.ptr(gf), nvec, nant, nft, _dev.ptr(W), nbl,
+                  _dev.host_ptr(idx.adj_ptr), _dev.ptr(adj_ptr), _dev.ptr(adj_b), _dev.ptr(adj_o),
+                  int(idx.adj_b.size), _dev.ptr(yf), st)
+        want = _dev.empty((nvec, n), torch.float64)
+        _dev.call("hydra_gain_basis_adj", _dev.ptr(yf), nvec, nant, nmodes, nft, _dev.ptr(F), _dev.ptr(ps),
+                  _dev.ptr(add), _dev.ptr(want), st)
+        ws = _dev.workspace(_dev._lib.query("hydra_gain_operator_blocks_workspace_bytes", nant, nft))
+        got = torch.full((nvec, n), float("nan"), dtype=torch.float64, device=dev)
+        _dev.call("hydra_gain_operator_blocks", _dev.ptr(X), nvec, nant, nmodes, nft, _dev.ptr(F),
+                  _dev.ptr(ps), _dev.ptr(Wb), _dev.ptr(sw), _dev.ptr(add), _dev.ptr(got), _dev.ptr(ws),
+                  ws.numel(), st)
+        assert float((got - want).abs().max()) <= 1e-12 * float(want.abs().max()), nmodes
+
+
 @pytest.mark.parametrize("nant,nf,nt,holes,flip", [(12, 3, 5, False, False), (40, 4, 8, True, False),
                                                    (9, 1, 3, False, False), (380, 3, 7, True, False),
                                                    (14, 2, 5, False, True)])
