@@ -252,6 +252,8 @@ def main_sh_streamed(args, comm, rank, world, dev):
     prior_std, sigma_noise = 0.1, 0.05
     inv_prior = torch.full((nm,), 1.0 / prior_std ** 2, dtype=torch.float64, device=dev)
     inv_noise = torch.full((m_loc,), 1.0 / sigma_noise ** 2, dtype=torch.float64, device=dev)
+    if args.flags > 0.0:      # flagged samples: the closed-form left-hand side takes its correction
+        inv_noise[torch.rand(m_loc, device=dev, generator=gen) < args.flags] = 0.0
     a_true = prior_std * torch.randn(nm, dtype=torch.float64, device=dev, generator=gen_a)
     data = op.apply(a_true).reshape(-1)
     data += sigma_noise * torch.randn(m_loc, dtype=torch.complex128, device=dev, generator=gen)
@@ -324,8 +326,11 @@ def main_sh_streamed(args, comm, rank, world, dev):
         },
         "setup_voltages_s": t_volt, "setup_lhs_matrix_s": t_lhs,
         "setup_lhs_path": ("closed form through pixel space (baseline-independent weights, complete array)"
+                           + (f" minus the Gram of {op.last_lhs_flagged_rows} flagged rows"
+                              if getattr(op, "last_lhs_flagged_rows", 0) else "")
                            if op.fac.last_gram_kernel == "gram_uniform_kernel" else
                            "Gram of the regenerated operator, LST block by LST block"),
+        "flagged_fraction": args.flags,
         "setup_lhs_tflops_operator_form": (2.0 * m_loc * op.npix * nm + 2.0 * m_loc * nm * (nm + 1)) / t_lhs / 1e12,
         "sample_rel_residual": resid,
         "roofline": ({

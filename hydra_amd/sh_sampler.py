@@ -316,13 +316,21 @@ class StreamedSHOperator:
     #: bytes of scaled voltages the closed-form left-hand side keeps at a time (a frequency chunk)
     LHS_CHUNK_BYTES = 16 << 30
 
-    def _lhs_closed_form(self, w_ft):
-        """Re(R^H N^-1 R) for baseline-independent weights ``w_ft`` (Nf*Nt,) through pixel space:
+    def _lhs_closed_form(self, w):
+        """Re(R^H N^-1 R) for weights ``w`` (Nbl, Nf, Nt) that do not depend on the baseline -- or
+        do so only through flagged / down-weighted samples -- through pixel space:
         R = P Y, so Re(R^H W R) = Y^T Re(P^H W P) Y, and for a complete array the pixel Gram
         Re(P^H W P) has the closed form in the antenna voltages of csrc/gram.hip
         (``gram_uniform_kernel``: a rank-Nant update per (f,t) where the operator's Gram is a
         rank-Nbl one) -- 3.8 s -> 0.5 s at config 3, no block of the operator is ever formed.
-        Only the pixels above the horizon at some LST of the run enter it."""
+        Only the pixels above the horizon at some LST of the run enter it.
+
+        Flags (sh_sampler.py:389-402 accepts any ``inv_noise_var``; real data is always flagged):
+        Re(P^H W P) = G_closed(w_ref) - sum over flagged (b,f,t) of (w_ref - w) conj(P_b) P_b with
+        w_ref the common weight of the (f,t) sample -- the correction of the point-source head
+        (``FactoredProj.gram``: ``hydra_flagged_rows`` + ``hydra_gram`` + ``hydra_gram_subtract``)
+        in pixel space, one frequency chunk at a time so the flagged rows of a chunk (rows x
+        visible pixels) stay a few GB.  Returns None when some chunk's weights are neither."""
         nf, nt, nant, npix = self.V.shape
         # pixels that are above the horizon at some LST of the run (the others have zero voltage
         # at every (f,t): exact zeros in the Gram); the Gram's cost goes with their number squared
@@ -337,13 +345,19 @@ class StreamedSHOperator:
         per_chan = nt * (nant + 1) * nv * 16 * (1 if idx is None else 2)
         step = max(1, int(self.LHS_CHUNK_BYTES // per_chan))
         Gp = None
+        self.last_lhs_flagged_rows = 0
         for j0 in range(0, nf, step):
             j1 = min(nf, j0 + step)
             sub = self.fac.channels(j0, j1)
             if idx is not None:
                 sub.V = self.V[j0:j1].index_select(3, idx)
                 sub.shape = tuple(sub.shape[:3]) + (nv,)
-            G = sub.gram(None, None, plan=("uniform", w_ft[j0 * nt:j1 * nt].contiguous()))
+            wc = w[:, j0:j1].contiguous()
+            plan = sub._noise_plan(wc)
+            if plan[0] == "general":
+                return None
+            G = sub.gram(None, wc, plan=plan)
+            self.last_lhs_flagged_rows += int(getattr(sub, "last_gram_flagged_rows", 0))
             Gp = G if Gp is None else Gp.add_(G)
             del sub
         self.fac.last_gram_kernel = "gram_uniform_kernel"
@@ -360,9 +374,7 @@ class StreamedSHOperator:
         ip = _dev.f64(inv_prior_var)
         A = None
         if closed_form and self.fac.complete and self.fac.allow_uniform and self.V.shape[2] > 1:
-            plan = self.fac._noise_plan(w)
-            if plan[0] == "uniform":
-                A = self._lhs_closed_form(plan[1])
+            A = self._lhs_closed_form(w)
         if A is None:
             A = self._lhs_blocks(w)
         if comm is not None:

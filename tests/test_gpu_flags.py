@@ -122,3 +122,48 @@ def test_flagged_closed_form_equals_general_kernel_at_config2_full_size():
     y = fac.apply(x, rowmul=gg)
     quad = torch.sum(w * (y.real ** 2 + y.imag ** 2)).item()
     assert abs(torch.dot(x, G_f @ x).item() - quad) <= 1e-11 * abs(quad)
+
+
+def test_streamed_sh_left_hand_side_with_flags_matches_oracle():
+    """StreamedSHOperator.lhs_matrix with flagged data (sh_sampler.py:389-402 takes any
+    inv_noise_var): the closed form through pixel space at the common weight of each (f,t) sample
+    minus the Gram of the flagged rows, frequency chunk by frequency chunk -- against the
+    oracle's Re(R^H N^-1 R) + S^-1 and against the block-accumulated path; weights that depend on
+    the baseline everywhere still take the block path."""
+    import torch
+    import hydra_amd as hy
+    from hydra_amd import sh_sampler
+    from oracle import beams as obeams, gcr_sh, helpers
+    LAT = -30.7215 * np.pi / 180.0
+    ant_pos = helpers.build_hex_array((3, 4))
+    freqs, lsts = np.linspace(100.0, 120.0, 5), np.linspace(0.2, 0.5, 4)
+    lmax, nside = 6, 8
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bo = [obeams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    R_ref, _, _, _ = gcr_sh.vis_proj_operator_no_rot(freqs, lsts, bo, ant_pos, lmax, nside,
+                                                     latitude=LAT)
+    op = sh_sampler.StreamedSHOperator(freqs, lsts, bh, ant_pos, lmax, nside, latitude=LAT)
+    mrows, nm = R_ref.shape
+    rng = np.random.RandomState(23)
+    w = _flagged_noise(op.nbl, op.nf, op.nt, rng, frac=0.03)
+    ip = 50.0 + 50.0 * rng.rand(nm)
+    wf = w.reshape(-1)
+    A_ref = R_ref.real.T @ (wf[:, None] * R_ref.real) + R_ref.imag.T @ (wf[:, None] * R_ref.imag) \
+        + np.diag(ip)
+    n_dev = int((w != w.max(axis=0, keepdims=True)).sum())
+    for chunk_bytes in (16 << 30, 1):              # all channels at once / one channel at a time
+        op.LHS_CHUNK_BYTES = chunk_bytes
+        A = op.lhs_matrix(w, ip).cpu().numpy()
+        assert op.fac.last_gram_kernel == "gram_uniform_kernel"
+        assert op.last_lhs_flagged_rows == n_dev > 0
+        assert relerr(A, A_ref) < 1e-10 and np.array_equal(A, A.T)
+    A_bl = op.lhs_matrix(w, ip, closed_form=False).cpu().numpy()
+    assert op.fac.last_gram_kernel == "gram_kernel" and relerr(A_bl, A_ref) < 1e-10
+    # per-baseline weights everywhere: no closed form
+    w3 = 100.0 + 800.0 * rng.rand(op.nbl, op.nf, op.nt)
+    A3 = op.lhs_matrix(w3, ip).cpu().numpy()
+    assert op.fac.last_gram_kernel == "gram_kernel"
+    w3f = w3.reshape(-1)
+    A3_ref = R_ref.real.T @ (w3f[:, None] * R_ref.real) + R_ref.imag.T @ (w3f[:, None] * R_ref.imag) \
+        + np.diag(ip)
+    assert relerr(A3, A3_ref) < 1e-10
