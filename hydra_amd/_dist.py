@@ -43,6 +43,63 @@ def init_from_env(backend=None):
     return Comm()
 
 
+#: rows per block of the block-cyclic row layout of a sharded operator (= the super-panel width of
+#: the row-sharded factorisation, a multiple of its 256-wide panels)
+ROW_BLOCK = 2048
+
+
+class RowLayout:
+    """Block-cyclic rows of an n-row matrix over ``size`` ranks: global row block q (``block``
+    rows, the last one shorter) belongs to rank q % size, and a rank keeps its blocks one after
+    the other in ascending order.  A right-looking factorisation works on the rows below the
+    current column: with contiguous row blocks the last rank had 2 - 1/size times the mean work
+    and the first ones ran dry early; cyclic blocks give every rank the same share at every
+    stage.  ``block`` is a multiple of 256 (a 256-wide diagonal block never straddles two owners):
+    2048 when every rank gets at least four such blocks, smaller for small matrices."""
+
+    def __init__(self, n, size, rank, block=None):
+        self.n, self.size, self.rank = int(n), int(size), int(rank)
+        if block is None:
+            block = 256 * max(1, min(ROW_BLOCK // 256, self.n // (self.size * 4 * 256)))
+        assert block % 256 == 0
+        self.block = int(block)
+        self.nblocks = -(-self.n // self.block)
+        self._rows = {}
+
+    def owner(self, blk):
+        return blk % self.size
+
+    def block_range(self, blk):
+        """Global rows [g0, g1) of block ``blk``."""
+        return blk * self.block, min((blk + 1) * self.block, self.n)
+
+    def local_start(self, blk):
+        """First local row of block ``blk`` on its owner (all of an owner's earlier blocks are full)."""
+        return (blk // self.size) * self.block
+
+    def blocks_of(self, rank=None):
+        return range(self.rank if rank is None else rank, self.nblocks, self.size)
+
+    def nloc(self, rank=None):
+        return sum(g1 - g0 for g0, g1 in map(self.block_range, self.blocks_of(rank)))
+
+    @property
+    def maxloc(self):
+        return max(self.nloc(k) for k in range(self.size))
+
+    def rows(self, rank=None):
+        """Global indices of a rank's rows in local order (numpy int64, ascending)."""
+        rank = self.rank if rank is None else rank
+        if rank not in self._rows:
+            parts = [np.arange(*self.block_range(b), dtype=np.int64) for b in self.blocks_of(rank)]
+            self._rows[rank] = np.concatenate(parts) if parts else np.zeros(0, dtype=np.int64)
+        return self._rows[rank]
+
+    def local_index(self, g):
+        """Number of this rank's rows with global index < g."""
+        return int(np.searchsorted(self.rows(), g))
+
+
 class Comm:
     def __init__(self, group=None, ranks=None):
         self.group = group                     # None = world
@@ -123,37 +180,44 @@ class Comm:
         return [p.to(t.device) for p in parts] if isinstance(t, torch.Tensor) else parts
 
     # ---- row sharding of a dense operator (large-N solve)
-    def row_range(self, n, rank=None):
-        """Rows [r0, r1) of an n-row matrix owned by ``rank`` (default: this rank): blocks of
-        ceil(n / size) rows, the last one shorter (possibly empty)."""
-        size = self.Get_size()
-        rank = self.Get_rank() if rank is None else rank
-        per = -(-n // size)
-        return min(rank * per, n), min((rank + 1) * per, n)
+    def row_layout(self, n, block=None):
+        """The block-cyclic row layout of an n-row operator over this communicator's ranks."""
+        key = (int(n), block)
+        cache = self.__dict__.setdefault("_layouts", {})
+        if key not in cache:
+            cache[key] = RowLayout(n, self.Get_size(), self.Get_rank(), block)
+        return cache[key]
 
     def reduce_rows_(self, A):
-        """Sum the (n, ncols) partial matrices of all ranks block row by block row, each block
-        to the rank that owns it.  Returns this rank's rows; the rows of ``A`` are left in an
-        unspecified state.
+        """Sum the (n, ncols) partial matrices of all ranks, each row block to the rank that owns
+        it in ``row_layout(n)``.  Returns this rank's rows (nloc, ncols) as a new tensor; the rows of
+        ``A`` are left in an unspecified state.
 
-        RCCL: ONE reduce-scatter (``reduce_scatter_tensor``) when the rows divide evenly over the
-        ranks -- every GPU then sends and receives on all of its xGMI links at once, where a
-        loop of ``size`` rooted reduces serialises them (0.13 s against 0.9 s for
-        the 80 GB Gram of config 5 on 8 GPUs).  The result is a new (n/size, ncols) tensor: the
-        collective's output may not alias its input.  Otherwise (gloo, or a ragged last block)
-        one in-place reduce per block on views of ``A``."""
+        RCCL: one reduce-scatter (``reduce_scatter_tensor``) per ROUND of ``size`` consecutive full
+        blocks -- a round is contiguous in ``A`` and its k-th piece belongs to rank k -- so every GPU
+        sends and receives on all of its xGMI links at once, where a loop of rooted reduces
+        serialises them (0.13 s against 0.9 s for the 80 GB Gram of config 5 on 8
+        GPUs); the collective writes straight into the rank's rows.  Otherwise (gloo, or the ragged
+        last round) one rooted reduce per block."""
         n = A.shape[0]
-        size = self.Get_size()
-        if self.backend == "nccl" and A.is_cuda and A.is_contiguous() and n % size == 0:
-            out = torch.empty((n // size,) + tuple(A.shape[1:]), dtype=A.dtype, device=A.device)
-            dist.reduce_scatter_tensor(out, A, op=dist.ReduceOp.SUM, group=self.group)
-            return out
-        for k in range(size):
-            r0, r1 = self.row_range(n, k)
-            if r1 > r0:
-                self.reduce_(A[r0:r1], root=k)
-        r0, r1 = self.row_range(n)
-        return A[r0:r1]
+        lay = self.row_layout(n)
+        size, rank, B = lay.size, lay.rank, lay.block
+        out = torch.empty((lay.nloc(),) + tuple(A.shape[1:]), dtype=A.dtype, device=A.device)
+        fast = self.backend == "nccl" and A.is_cuda and A.is_contiguous()
+        for rd in range(-(-lay.nblocks // size)):
+            b0 = rd * size
+            full = (b0 + size) * B <= n
+            if fast and full:
+                dist.reduce_scatter_tensor(out[rd * B:(rd + 1) * B], A[b0 * B:(b0 + size) * B],
+                                           op=dist.ReduceOp.SUM, group=self.group)
+                continue
+            for blk in range(b0, min(b0 + size, lay.nblocks)):
+                g0, g1 = lay.block_range(blk)
+                self.reduce_(A[g0:g1], root=lay.owner(blk))
+                if lay.owner(blk) == rank:
+                    l0 = lay.local_start(blk)
+                    out[l0:l0 + g1 - g0].copy_(A[g0:g1])
+        return out
 
     def _sym_packed(self, A):
         from . import _dev
@@ -200,19 +264,32 @@ class Comm:
         return out
 
     def allgather_rows(self, part, n):
-        """Concatenate the ranks' row-block vectors (lengths as in ``row_range``) into the full
-        length-n vector on every rank."""
-        size = self.Get_size()
-        per = -(-n // size)
+        """The full length-n vector, on every rank, from the ranks' pieces in ``row_layout(n)``
+        (``part``: this rank's rows in local order)."""
+        lay = self.row_layout(n)
+        size, per = lay.size, max(lay.maxloc, 1)
         pad = torch.zeros(per, dtype=part.dtype, device=part.device)
         pad[: part.numel()] = part
         s, _ = self._stage(pad)
-        out = torch.empty(size * per, dtype=s.dtype, device=s.device)
+        got = torch.empty(size * per, dtype=s.dtype, device=s.device)
         if self.backend == "nccl":
-            dist.all_gather_into_tensor(out, s, group=self.group)
+            dist.all_gather_into_tensor(got, s, group=self.group)
         else:
-            dist.all_gather(list(out.split(per)), s, group=self.group)
-        return out[:n].to(part.device)
+            dist.all_gather(list(got.split(per)), s, group=self.group)
+        got = got.to(part.device)
+        out = torch.empty(n, dtype=part.dtype, device=part.device)
+        for k in range(size):
+            idx = self._rows_dev(lay, k, part.device)
+            if idx.numel():
+                out[idx] = got[k * per:k * per + idx.numel()]
+        return out
+
+    def _rows_dev(self, lay, rank, device):
+        cache = self.__dict__.setdefault("_rows_dev_cache", {})
+        key = (lay.n, lay.block, rank, str(device))
+        if key not in cache:
+            cache[key] = torch.as_tensor(lay.rows(rank), device=device)
+        return cache[key]
 
     # ---- mpi4py-style buffer collectives
     def Bcast(self, buf, root=0):

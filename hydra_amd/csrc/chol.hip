@@ -46,8 +46,9 @@ __device__ __forceinline__ bool potrf_wave(double (&v)[NB], int i) {
 
 // factor the nb x nb diagonal block at (k,k) in place from the tile `t` in LDS (rows/cols >= nb
 // are treated as identity); called by the first wave of a workgroup.
-__device__ __forceinline__ void potrf_tile(const double (*t)[NB + 1], double* __restrict__ A, int n,
-                                           int k, int nb, int32_t* __restrict__ info, int lane) {
+__device__ __forceinline__ void potrf_tile(const double (*t)[NB + 1], double* __restrict__ A,
+                                           size_t ld, int k, int nb, int32_t* __restrict__ info,
+                                           int lane) {
   int i = lane & (NB - 1);
   double v[NB];
 #pragma unroll
@@ -55,23 +56,25 @@ __device__ __forceinline__ void potrf_tile(const double (*t)[NB + 1], double* __
   bool bad = potrf_wave(v, i);
   if (bad && lane == 0) atomicOr(info, 1);
   if (lane < nb) {
-    double* row = A + (size_t)(k + lane) * n + k;
+    double* row = A + (size_t)(k + lane) * ld + k;
 #pragma unroll
     for (int j = 0; j < NB; ++j)
       if (j <= lane) row[j] = v[j];
   }
 }
 
-// first diagonal block (the later ones are factored by the trailing update that completes them)
+// first diagonal block (the later ones are factored by the trailing update that completes them).
+// Throughout the 32-wide kernels: ld = leading dimension, n = rows (= columns for a whole matrix;
+// a standalone panel -- hydra_chol_panel -- has more rows than columns and ld = its width).
 __global__ void __launch_bounds__(NB * NB)
-potrf_diag_kernel(double* __restrict__ A, int n, int k, int32_t* __restrict__ info) {
+potrf_diag_kernel(double* __restrict__ A, size_t ld, int n, int k, int32_t* __restrict__ info) {
   __shared__ double s[NB][NB + 1];
   int i = threadIdx.y, j = threadIdx.x;
   int nb = min(NB, n - k);
-  s[i][j] = (i < nb && j < nb) ? A[(size_t)(k + i) * n + k + j] : (i == j ? 1.0 : 0.0);
+  s[i][j] = (i < nb && j < nb) ? A[(size_t)(k + i) * ld + k + j] : (i == j ? 1.0 : 0.0);
   __syncthreads();
   int tid = i * NB + j;
-  if (tid < 64) potrf_tile(s, A, n, k, nb, info, tid);
+  if (tid < 64) potrf_tile(s, A, ld, k, nb, info, tid);
 }
 
 // rows below a full diagonal block: A[r, k:k+NB] <- A[r, k:k+NB] L11^-T, thread <-> row.  One wave
@@ -80,7 +83,7 @@ potrf_diag_kernel(double* __restrict__ A, int n, int k, int32_t* __restrict__ in
 constexpr int TRSM_T = 64;
 static_assert(TRSM_T == 2 * NB, "trsm staging assumes two rows per trip");
 __global__ void __launch_bounds__(TRSM_T)
-trsm_panel_kernel(double* __restrict__ A, int n, int k) {
+trsm_panel_kernel(double* __restrict__ A, size_t ld, int n, int k) {
   __shared__ double l[NB][NB + 1];
   __shared__ double dinv[NB];
   __shared__ double rows[TRSM_T][NB + 1];
@@ -92,9 +95,9 @@ trsm_panel_kernel(double* __restrict__ A, int n, int k) {
     const int j = tid % NB, i0 = tid / NB;   // TRSM_T / NB = 2 rows per trip
     double a[NB / 2], rr[NB];
 #pragma unroll
-    for (int q = 0; q < NB / 2; ++q) a[q] = A[(size_t)(k + i0 + 2 * q) * n + k + j];
+    for (int q = 0; q < NB / 2; ++q) a[q] = A[(size_t)(k + i0 + 2 * q) * ld + k + j];
 #pragma unroll
-    for (int q = 0; q < NB; ++q) rr[q] = A[(size_t)min(r0 + i0 + 2 * q, n - 1) * n + k + j];
+    for (int q = 0; q < NB; ++q) rr[q] = A[(size_t)min(r0 + i0 + 2 * q, n - 1) * ld + k + j];
 #pragma unroll
     for (int q = 0; q < NB / 2; ++q) {
       int i = i0 + 2 * q;
@@ -121,7 +124,7 @@ trsm_panel_kernel(double* __restrict__ A, int n, int k) {
 #pragma unroll
   for (int q = 0; q < NB; ++q) {
     int i = tid / NB + 2 * q, j = tid % NB;
-    if (r0 + i < n) A[(size_t)(r0 + i) * n + k + j] = rows[i][j];
+    if (r0 + i < n) A[(size_t)(r0 + i) * ld + k + j] = rows[i][j];
   }
 }
 
@@ -134,7 +137,7 @@ trsm_panel_kernel(double* __restrict__ A, int n, int k) {
 // matrix cores instead (chol_syrk_mfma_kernel).
 constexpr int SY_T = 64;
 __global__ void __launch_bounds__(256)
-syrk_update_kernel(double* __restrict__ A, int n, int k, int col_end,
+syrk_update_kernel(double* __restrict__ A, size_t ld, int n, int k, int col_end,
                    int32_t* __restrict__ info) {
   const int base = k + NB;
   const int bi = blockIdx.y, bj = blockIdx.x;
@@ -147,8 +150,8 @@ syrk_update_kernel(double* __restrict__ A, int n, int k, int col_end,
     double pa[SY_T / 8], pb[SY_T / 8];
 #pragma unroll
     for (int q = 0; q < SY_T / 8; ++q) {
-      pa[q] = A[(size_t)min(i0 + r + 8 * q, n - 1) * n + k + c];
-      pb[q] = A[(size_t)min(j0 + r + 8 * q, n - 1) * n + k + c];
+      pa[q] = A[(size_t)min(i0 + r + 8 * q, n - 1) * ld + k + c];
+      pb[q] = A[(size_t)min(j0 + r + 8 * q, n - 1) * ld + k + c];
     }
 #pragma unroll
     for (int q = 0; q < SY_T / 8; ++q) {
@@ -162,7 +165,7 @@ syrk_update_kernel(double* __restrict__ A, int n, int k, int col_end,
 #pragma unroll
     for (int b = 0; b < 4; ++b) {
       int gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
-      old[a][b] = (gi < n && gj <= gi) ? A[(size_t)gi * n + gj] : 0.0;
+      old[a][b] = (gi < n && gj <= gi && gj < col_end) ? A[(size_t)gi * ld + gj] : 0.0;
     }
   __syncthreads();
   double acc[4][4] = {};
@@ -188,11 +191,11 @@ syrk_update_kernel(double* __restrict__ A, int n, int k, int col_end,
       int gi = i0 + li, gj = j0 + lj;
       double val = old[a][b] - acc[a][b];
       if (corner && li < NB && lj < NB) sa[li][lj] = val;
-      else if (gi < n && gj <= gi && gj < col_end) A[(size_t)gi * n + gj] = val;
+      else if (gi < n && gj <= gi && gj < col_end) A[(size_t)gi * ld + gj] = val;
     }
   if (!corner) return;
   __syncthreads();
-  if (tid < 64) potrf_tile(sa, A, n, base, min(NB, n - base), info, tid);
+  if (tid < 64) potrf_tile(sa, A, ld, base, min(NB, n - base), info, tid);
 }
 
 // Both triangular solves of the Cholesky fallback in ONE launch by one workgroup of NB*NB threads
@@ -536,6 +539,51 @@ chol_bwd_update_kernel(const double* __restrict__ A, int n, int k, int nb, doubl
   for (; r < nb; ++r) s0 += col[(size_t)r * n] * xk[r];
   if (c < k) b[c] -= s0 + s1;
 }
+
+// y[i] -= sum_j M[i][j] x[j] for an nrows x ncols piece of a row-major matrix (leading dimension
+// ld): one wave per row, the lanes along the row.  The forward sweep of the row-sharded solve: a
+// rank's rows below a solved block take that block's part of the solution.
+__global__ void __launch_bounds__(256)
+rows_update_kernel(const double* __restrict__ M, size_t ld, int nrows, int ncols,
+                   const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wave; i < nrows; i += gridDim.x * 4) {
+    const double* row = M + (size_t)i * ld;
+    double s0 = 0.0, s1 = 0.0;
+    int j = lane;
+    for (; j + 64 < ncols; j += 128) {
+      s0 += row[j] * x[j];
+      s1 += row[j + 64] * x[j + 64];
+    }
+    if (j < ncols) s0 += row[j] * x[j];
+    const double t = wave_sum(s0 + s1);
+    if (lane == 0) y[i] -= t;
+  }
+}
+
+// b[j] -= sum_i M[i][j] x[i], j < ncols: one thread per column, coalesced along the rows of M.  The
+// backward sweep: the columns left of a solved block take that block's rows.
+__global__ void __launch_bounds__(256)
+cols_update_kernel(const double* __restrict__ M, size_t ld, int nrows, int ncols,
+                   const double* __restrict__ x, double* __restrict__ b) {
+  const int c = blockIdx.x * 256 + threadIdx.x;
+  const int cc = min(c, ncols - 1);
+  const double* col = M + cc;
+  double s0 = 0.0, s1 = 0.0;
+  int r = 0;
+  for (; r + 8 <= nrows; r += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + u) * ld];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0 += v[u] * x[r + u];
+      s1 += v[u + 1] * x[r + u + 1];
+    }
+  }
+  for (; r < nrows; ++r) s0 += col[(size_t)r * ld] * x[r];
+  if (c < ncols) b[c] -= s0 + s1;
+}
 }  // namespace hydra
 
 using namespace hydra;
@@ -557,20 +605,35 @@ static int chol_small_solve(const double* A, double* b, int n, hipStream_t s) {
   return HYDRA_OK;
 }
 
+static int chol_solve_blocked(const double* A, double* b, int n, hipStream_t s);
+
+// The two triangular solves.  One workgroup streams L through one CU (n = 2000: 0.93 ms, 40 % of
+// the whole dense solve and 15 % of a sample that reuses the factor); from 1024 unknowns on the
+// panel-wise form takes over -- 256 x 256 diagonal blocks by that workgroup, the rest of L by many
+// (n = 2000: 32 short launches).  Both callers of a given n take the same route, so a solve from a
+// kept factor (hydra_chol_apply) repeats hydra_chol_solve bit for bit.
+static constexpr int CHOL_SOLVE_BLOCKED_MIN_N = 1024;
+static int chol_solve_any(const double* A, double* b, int n, hipStream_t s) {
+  if (n >= CHOL_SOLVE_BLOCKED_MIN_N && n % 2 == 0 && reinterpret_cast<uintptr_t>(A) % 16 == 0 &&
+      reinterpret_cast<uintptr_t>(b) % 16 == 0)
+    return chol_solve_blocked(A, b, n, s);
+  return chol_small_solve(A, b, n, s);
+}
+
 static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_t s) {
   dim3 tb(NB, NB);
-  potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, 0, info_dev);
+  potrf_diag_kernel<<<1, tb, 0, s>>>(A, (size_t)n, n, 0, info_dev);
   for (int k = 0; k < n; k += NB) {
     int nb = std::min(NB, n - k);
     int rest = n - k - nb;
     if (rest > 0) {   // then the block is full (nb == NB)
-      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, k);
+      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, (size_t)n, n, k);
       int nblk = (rest + SY_T - 1) / SY_T;
-      syrk_update_kernel<<<dim3(nblk, nblk), 256, 0, s>>>(A, n, k, n, info_dev);  // + potrf of block k+NB
+      syrk_update_kernel<<<dim3(nblk, nblk), 256, 0, s>>>(A, (size_t)n, n, k, n, info_dev);  // + potrf of block k+NB
     }
   }
   HYDRA_CHECK_LAUNCH("hydra_chol_solve(factor)");
-  return b ? chol_small_solve(A, b, n, s) : HYDRA_OK;
+  return b ? chol_solve_any(A, b, n, s) : HYDRA_OK;
 }
 
 // Columns are finished 256 at a time (32-wide steps capped at the sub-panel's last column), but the
@@ -587,22 +650,30 @@ static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_
 static constexpr int SPW = HYDRA_CHOL_SPW;
 static_assert(SPW % PB == 0, "super-panel = whole 256-wide panels");
 
-static int chol_factor_blocked(double* A, int n, int32_t* info_dev, hipStream_t s) {
+// Columns [k, col_end) of the n-row array A (leading dimension ld) by the 32-wide steps: the diagonal
+// block at (k,k) is factored, the rows below it solved against it, and the columns still inside
+// [k, col_end) updated after every step (the update that completes a 32-block factors it).
+static void factor_panel(double* A, size_t ld, int n, int k, int col_end, int32_t* info_dev,
+                         hipStream_t s) {
   dim3 tb(NB, NB);
+  potrf_diag_kernel<<<1, tb, 0, s>>>(A, ld, n, k, info_dev);
+  for (int kk = k; kk < col_end; kk += NB) {
+    const int nb = std::min(NB, n - kk), rest = n - kk - nb;
+    if (rest <= 0) break;
+    trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, ld, n, kk);
+    const int ncols = col_end - (kk + NB);
+    if (ncols > 0)   // update the panel's remaining columns (+ potrf of the next 32-block)
+      syrk_update_kernel<<<dim3((ncols + SY_T - 1) / SY_T, (rest + SY_T - 1) / SY_T), 256, 0, s>>>(
+          A, ld, n, kk, col_end, info_dev);
+  }
+}
+
+static int chol_factor_blocked(double* A, int n, int32_t* info_dev, hipStream_t s) {
   for (int k0 = 0; k0 < n; k0 += SPW) {
     const int sp_end = std::min(k0 + SPW, n);
     for (int k = k0; k < sp_end; k += PB) {
       const int pb = std::min(PB, n - k), col_end = k + pb;
-      potrf_diag_kernel<<<1, tb, 0, s>>>(A, n, k, info_dev);
-      for (int kk = k; kk < col_end; kk += NB) {
-        const int nb = std::min(NB, n - kk), rest = n - kk - nb;
-        if (rest <= 0) break;
-        trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, n, kk);
-        const int ncols = col_end - (kk + NB);
-        if (ncols > 0)   // update the panel's remaining columns (+ potrf of the next 32-block)
-          syrk_update_kernel<<<dim3((ncols + SY_T - 1) / SY_T, (rest + SY_T - 1) / SY_T), 256, 0, s>>>(
-              A, n, kk, col_end, info_dev);
-      }
+      factor_panel(A, (size_t)n, n, k, col_end, info_dev, s);
       const int wrest = sp_end - col_end;        // columns of the super-panel still to be factored
       if (wrest > 0) {                            // then this sub-panel is full (pb == PB)
         const int mrows = n - col_end;
@@ -658,8 +729,7 @@ extern "C" {
 int hydra_chol_apply(const double* L, double* b, int n, void* stream) {
   HYDRA_CHECK_ARG(L && b && n > 0, "hydra_chol_apply: bad arguments");
   hipStream_t s = as_stream(stream);
-  if (chol_takes_blocked(L, b, n)) return chol_solve_blocked(L, b, n, s);
-  return chol_small_solve(L, b, n, s);
+  return chol_solve_any(L, b, n, s);
 }
 
 int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* stream) {
@@ -685,6 +755,40 @@ int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, voi
   int rc = chol_factor_blocked(A, n, info_dev, s);
   if (rc || !b) return rc;
   return chol_solve_blocked(A, b, n, s);
+}
+
+int hydra_chol_panel(double* P, long long ld, int nrows, int ncols, int32_t* info_dev, void* stream) {
+  HYDRA_CHECK_ARG(P && info_dev && ncols > 0 && nrows >= ncols && ld >= ncols,
+                  "hydra_chol_panel: bad arguments (nrows=%d ncols=%d ld=%lld)", nrows, ncols, ld);
+  HYDRA_CHECK_ARG(nrows == ncols || ncols % NB == 0,
+                  "hydra_chol_panel: a panel with rows below it must be whole 32-column steps");
+  factor_panel(P, (size_t)ld, nrows, 0, ncols, info_dev, as_stream(stream));
+  HYDRA_CHECK_LAUNCH("hydra_chol_panel");
+  return HYDRA_OK;
+}
+
+int hydra_trsv_block(const double* L, long long ld, int n, double* b, int transpose, void* stream) {
+  HYDRA_CHECK_ARG(L && b && n > 0 && ld >= n, "hydra_trsv_block: bad arguments (n=%d)", n);
+  const size_t b_bytes = (size_t)n * sizeof(double);
+  HYDRA_CHECK_ARG(b_bytes <= 96 * 1024, "hydra_trsv_block: n=%d exceeds the LDS-resident vector (12288)", n);
+  const int sw = transpose ? 1 : 0;
+  if (int rc = reserve_lds(reinterpret_cast<const void*>(trsv_fused_kernel<true>), b_bytes)) return rc;
+  trsv_fused_kernel<true><<<1, TRSV_T, b_bytes, as_stream(stream)>>>(L, (int)ld, n, b, sw, sw + 1);
+  HYDRA_CHECK_LAUNCH("hydra_trsv_block");
+  return HYDRA_OK;
+}
+
+int hydra_gemv_sub(const double* M, long long ld, int nrows, int ncols, const double* x, double* y,
+                   int transpose, void* stream) {
+  HYDRA_CHECK_ARG(M && x && y && nrows > 0 && ncols > 0 && ld >= ncols,
+                  "hydra_gemv_sub: bad arguments (%d x %d, ld=%lld)", nrows, ncols, ld);
+  if (transpose)
+    cols_update_kernel<<<(ncols + 255) / 256, 256, 0, as_stream(stream)>>>(M, (size_t)ld, nrows, ncols, x, y);
+  else
+    rows_update_kernel<<<std::min((nrows + 3) / 4, 8192), 256, 0, as_stream(stream)>>>(M, (size_t)ld, nrows,
+                                                                                   ncols, x, y);
+  HYDRA_CHECK_LAUNCH("hydra_gemv_sub");
+  return HYDRA_OK;
 }
 
 int hydra_chol_update_rect(double* C, long long ldc, const double* PA, long long lda,

@@ -356,23 +356,24 @@ def cho_solve(factor, bvec):
 
 class RowShardedOperator:
     """A dense operator sharded by rows over the ranks of ``comm`` (one process per GPU): rank k
-    keeps rows ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n).  Calling it with a full vector
-    returns the full product on every rank: the local row-block product
-    (``hydra_gemv_rows``, HBM-bound on 8 n_k n bytes) followed by one all-gather of n doubles
-    over RCCL.  Pass it as ``cg(None, b, linear_op=op)``: every rank then runs the same fused CG
-    steps on identical data and returns the same x, as ``cg(comm=...)`` does in the reference
-    (linear_solver.py:506-508).  This is the 1-D analogue of the reference's 2-D block layout
-    (``cg_mpi``, linear_solver.py:238-375) for matrices too large for one GPU's patience -- the
-    80 GB operator of 100 000 sources costs 7 ms per product on one GPU, 1/size of that here."""
+    keeps the rows ``comm.row_layout(n).rows(k)`` (block-cyclic, see ``_dist.RowLayout``) as
+    ``A_rows`` (n_k, n).  Calling it with a full vector returns the full product on every rank:
+    the local row-block product (``hydra_gemv_rows``, HBM-bound on 8 n_k n bytes) followed by one
+    all-gather of n doubles over RCCL.  Pass it as ``cg(None, b, linear_op=op)``: every rank then
+    runs the same fused CG steps on identical data and returns the same x, as ``cg(comm=...)``
+    does in the reference (linear_solver.py:506-508).  This is the 1-D analogue of the
+    reference's 2-D block layout (``cg_mpi``, linear_solver.py:238-375) for matrices too large for
+    one GPU's patience -- the 80 GB operator of 100 000 sources costs 7 ms per product on one GPU,
+    1/size of that here."""
 
     def __init__(self, comm, A_rows, n):
         self.comm = comm
         self.A = _dev.f64(A_rows)
         self.n = int(n)
-        r0, r1 = comm.row_range(self.n)
-        assert tuple(self.A.shape) == (r1 - r0, self.n), (tuple(self.A.shape), (r0, r1, self.n))
+        nloc = comm.row_layout(self.n).nloc()
+        assert tuple(self.A.shape) == (nloc, self.n), (tuple(self.A.shape), (nloc, self.n))
         assert self.A.is_contiguous()
-        self.y = torch.empty(max(r1 - r0, 1), dtype=torch.float64, device=self.A.device)
+        self.y = torch.empty(max(nloc, 1), dtype=torch.float64, device=self.A.device)
 
     def __call__(self, v):
         vd = _dev.f64(v)
@@ -386,49 +387,70 @@ class RowShardedOperator:
 
 #: columns per trailing update of the row-sharded factorisation (csrc/chol.hip: HYDRA_CHOL_SPW)
 SUPER_PANEL = 2048
+PANEL = 256
+
+
+def _addr(t, row, col):
+    """Device address of element (row, col) of a contiguous 2-D float64 tensor."""
+    return t.data_ptr() + (row * t.shape[1] + col) * 8
 
 
 class RowShardedFactor:
     """Cholesky factor of an operator sharded by rows over the ranks of ``comm`` (what
-    ``factor_dense_rows`` returns): rank k holds rows ``comm.row_range(n, k)`` of L in the lower
-    triangle of ``A``.  ``solve(b)`` runs the two triangular sweeps, block row by block row."""
+    ``factor_dense_rows`` returns): a rank's rows of L in the lower triangle of its rows ``A`` of
+    the operator (``comm.row_layout(n)``); what lies above the diagonal is still the operator.
+    ``solve(b)`` runs the two triangular sweeps block by block, each diagonal block by its owner
+    (``hydra_trsv_block``), the rest of L by everyone on their own rows (``hydra_gemv_sub``)."""
 
     def __init__(self, comm, A, n):
         self.comm, self.A, self.n = comm, A, n
+        self.lay = comm.row_layout(n)
 
     def solve(self, bvec):
-        comm, A, n = self.comm, self.A, self.n
-        size, rank = comm.Get_size(), comm.Get_rank()
-        dev = A.device
+        comm, A, n, lay = self.comm, self.A, self.n, self.lay
+        rank, st = lay.rank, _dev.stream_ptr()
+        multi = lay.size > 1
         b = _dev.f64(bvec)
         assert b.numel() == n
-        # L y = b, block row by block row
-        y = b.clone()
-        for s in range(size):
-            s0, s1 = comm.row_range(n, s)
-            if s1 <= s0:
-                continue
-            if rank == s:
-                rhs = y[s0:s1] - (A[:, :s0] @ y[:s0] if s0 > 0 else 0.0)
-                y[s0:s1] = torch.linalg.solve_triangular(A[:, s0:s1], rhs[:, None], upper=False)[:, 0]
-            comm.bcast_(y[s0:s1], root=s)
-        # L^T x = y, from the last block up
-        x = y
-        for s in range(size - 1, -1, -1):
-            s0, s1 = comm.row_range(n, s)
-            if s1 <= s0:
-                continue
-            c = torch.zeros(max(s0, 1), dtype=torch.float64, device=dev)
-            if rank == s:
-                xs = torch.linalg.solve_triangular(A[:, s0:s1].T, x[s0:s1][:, None], upper=True)[:, 0]
-                x[s0:s1] = xs
-                if s0 > 0:
-                    c[:s0] = A[:, :s0].T @ xs
-            comm.bcast_(x[s0:s1], root=s)
-            if s0 > 0:
-                comm.bcast_(c, root=s)
-                x[:s0] -= c[:s0]
-        return _dev.like(bvec, x)
+        nloc = lay.nloc()
+        # L y = b.  y_loc: this rank's entries in local order; a solved block goes to everyone,
+        # then every rank takes it out of its rows below
+        rows_d = comm._rows_dev(lay, rank, b.device)
+        y_loc = b[rows_d].contiguous() if nloc else torch.zeros(1, dtype=torch.float64, device=b.device)
+        z = torch.empty(n, dtype=torch.float64, device=b.device)
+        for blk in range(lay.nblocks):
+            g0, g1 = lay.block_range(blk)
+            o, l0 = lay.owner(blk), lay.local_start(blk)
+            zb = z[g0:g1]
+            if rank == o:
+                zb.copy_(y_loc[l0:l0 + g1 - g0])
+                _dev.call("hydra_trsv_block", _addr(A, l0, g0), n, g1 - g0, _dev.ptr(zb), 0, st)
+            if multi:
+                comm.bcast_(zb, root=o)
+            lb = lay.local_index(g1)
+            if nloc > lb:
+                _dev.call("hydra_gemv_sub", _addr(A, lb, g0), n, nloc - lb, g1 - g0, _dev.ptr(zb),
+                          y_loc.data_ptr() + lb * 8, 0, st)
+        # L^T x = y, from the last block up.  Every rank holds all of z; the owner of a block
+        # solves it and takes its rows out of everything above
+        c = torch.empty(n, dtype=torch.float64, device=b.device)
+        for blk in range(lay.nblocks - 1, -1, -1):
+            g0, g1 = lay.block_range(blk)
+            o, l0 = lay.owner(blk), lay.local_start(blk)
+            zb = z[g0:g1]
+            if rank == o:
+                _dev.call("hydra_trsv_block", _addr(A, l0, g0), n, g1 - g0, _dev.ptr(zb), 1, st)
+                if g0 > 0:
+                    c[:g0].zero_()
+                    _dev.call("hydra_gemv_sub", _addr(A, l0, 0), n, g1 - g0, g0, _dev.ptr(zb),
+                              _dev.ptr(c), 1, st)
+            if multi:
+                comm.bcast_(zb, root=o)
+                if g0 > 0:
+                    comm.bcast_(c[:g0], root=o)
+            if g0 > 0:
+                z[:g0] += c[:g0]
+        return _dev.like(bvec, z)
 
 
 def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
@@ -439,99 +461,112 @@ def solve_dense_rows(comm, A_rows, bvec, overwrite_a=False):
 
 
 def factor_dense_rows(comm, A_rows, overwrite_a=False, n=None):
-    """The factorisation half of the dense solve of the driver (``scipy.linalg.solve(A, b, assume_a='her')``,
-    example.py:940-947) for an operator sharded by rows over the ranks of ``comm`` -- the layout
-    ``precompute_mpi(..., shard_rows=True)`` leaves it in: rank k holds rows
-    ``comm.row_range(n, k)`` as ``A_rows`` (n_k, n).  Returns a ``RowShardedFactor`` whose
-    ``solve(b)`` (b (n,), the same on every rank) gives x (n,) on every rank; a caller whose
-    operator does not change between samples factors once and solves per sample.
+    """The factorisation half of the dense solve of the driver
+    (``scipy.linalg.solve(A, b, assume_a='her')``, example.py:940-947) for an operator sharded by
+    rows over the ranks of ``comm`` -- the layout ``precompute_mpi(..., shard_rows=True)`` leaves it
+    in: rank k holds the rows ``comm.row_layout(n).rows(k)`` (block-cyclic) as ``A_rows`` (n_k, n).
+    Returns a ``RowShardedFactor`` whose ``solve(b)`` (b (n,), the same on every rank) gives x (n,)
+    on every rank; a caller whose operator does not change between samples factors once and
+    solves per sample.
 
-    Right-looking Cholesky, every rank working on its own rows.  Columns are finished 256 at a
-    time: the 256 x 256 diagonal block is summed to all ranks (each owns some of its rows) and
-    factored by everyone, every rank solves its rows of the panel against it, and the panel is
-    all-gathered (n x 256 doubles).  As in the one-GPU routine (csrc/chol.hip, "super-panels") the
-    matrix right of a SUPER-panel of 2048 columns is updated once, with K = 2048, on the FP64 matrix
-    cores (``hydra_chol_update_rect``: one round trip of C per 2048 columns instead of per 256);
-    inside the super-panel the columns still to be factored take a rank-256 update from each
-    finished panel.  The two triangular solves then walk the row blocks in order, one broadcast per
-    block.  Work per rank is its rows' share of the triangle (the last block has 2 - 1/size times
-    the mean).  n must be even.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
+    Right-looking Cholesky, every rank working on its own rows, every step a kernel of this
+    library (csrc/chol.hip).  Columns are finished 256 at a time: the rank that owns the
+    256 x 256 diagonal block sends it to all, and every rank runs the one-GPU routine's 32-wide
+    panel steps (``hydra_chol_panel``) on that block stacked on ITS rows of the panel -- the block
+    is factored redundantly (8 short steps), the rows are solved against it -- in a buffer that is
+    then all-gathered (n x 256 doubles on every rank).  As in the one-GPU routine ("super-panels")
+    the matrix right of a SUPER-panel of 2048 columns is updated once, with K = 2048, on the FP64
+    matrix cores (``hydra_chol_update_rect``: one round trip of C per 2048 columns instead of per
+    256); inside the super-panel the columns still to be factored take a rank-256 update from each
+    finished panel.  With block-cyclic rows every rank's share of the rows below the current column
+    is the same at every stage (contiguous blocks left the last rank 2 - 1/size times the mean
+    work).  n must be even.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
     A = _dev.f64(A_rows)
     if not (overwrite_a and A is A_rows):
         A = A.clone()
     n = int(A.shape[1]) if n is None else int(n)
-    size, rank = comm.Get_size(), comm.Get_rank()
-    r0, r1 = comm.row_range(n)
-    nloc = r1 - r0
-    assert tuple(A.shape) == (nloc, n) and A.is_contiguous(), (tuple(A.shape), (r0, r1, n))
-    assert n % 2 == 0, "solve_dense_rows: n must be even (rows are moved in 16-byte pieces)"
-    per = -(-n // size)
+    lay = comm.row_layout(n)
+    size, rank, B = lay.size, lay.rank, lay.block
+    nloc, maxloc = lay.nloc(), max(lay.maxloc, 1)
+    assert tuple(A.shape) == (nloc, n) and A.is_contiguous(), (tuple(A.shape), (nloc, n))
+    assert n % 2 == 0, "factor_dense_rows: n must be even (rows are moved in 16-byte pieces)"
     dev, st = A.device, _dev.stream_ptr()
-    PBW, SPW = 256, SUPER_PANEL
+    multi = size > 1
     info = _dev.zeros((1,), torch.int32)
     bad = _dev.zeros((1,), torch.int32)
-    dummy = torch.zeros(PBW, dtype=torch.float64, device=dev)
-    # (rows above the panel's end are never read from these: no clearing per panel)
-    mine = torch.zeros((per, PBW), dtype=torch.float64, device=dev)
-    panel = torch.empty((size * per, PBW), dtype=torch.float64, device=dev)
-    spanel = torch.empty((size * per, SPW), dtype=torch.float64, device=dev) if n > SPW else None
+    # A rank's rows of the current panel, in local order, below PANEL spare rows: the diagonal block
+    # goes right above the first row that is below it, so [block; rows below] is one array
+    mine_ext = torch.zeros((PANEL + maxloc, PANEL), dtype=torch.float64, device=dev)
+    mine = mine_ext[PANEL:]
+    panel = torch.empty((size * maxloc, PANEL), dtype=torch.float64, device=dev) if multi else mine
+    spanel = torch.empty((size * maxloc, SUPER_PANEL), dtype=torch.float64, device=dev) \
+        if n > SUPER_PANEL else None
+    low = torch.ones((PANEL, PANEL), dtype=torch.bool, device=dev).tril()
 
-    def update(i0, c0, c1, k_lo, k_hi, pb_rows, ldb):
-        """My rows i >= i0 of columns [c0, c1) take the rank-(k_hi - k_lo) update from columns
-        [k_lo, k_hi) of my rows (PA) and of the gathered rows c0.. (PB)."""
-        if r1 <= i0 or c1 <= c0:
+    def update(c0, c1, k_lo, k_hi, src, ldb):
+        """My rows below column c0 of columns [c0, c1) take the rank-(k_hi - k_lo) update
+        C[i][j] -= sum_k A[i][k] L[j][k], k in [k_lo, k_hi): PA = my rows, PB = the gathered rows
+        of ``src`` (leading dimension ldb; rank o's local row l at o * maxloc + l), one column
+        block at a time -- the rows of a block sit together in ``src``."""
+        if c1 <= c0 or nloc == 0:
             return
-        mrows, ncols = r1 - i0, min(c1, r1) - c0
-        if ncols <= 0:
-            return
-        _dev.call("hydra_chol_update_rect", A.data_ptr() + ((i0 - r0) * n + c0) * 8, n,
-                  A.data_ptr() + ((i0 - r0) * n + k_lo) * 8, n, pb_rows, ldb, mrows, ncols,
-                  i0 - c0, k_hi - k_lo, st)
+        for cb in range(c0 // B, (c1 - 1) // B + 1):
+            g0, g1 = lay.block_range(cb)
+            j0, j1 = max(c0, g0), min(c1, g1)
+            o, l0 = lay.owner(cb), lay.local_start(cb)
+            pb_ptr = src.data_ptr() + ((o * maxloc + l0 + (j0 - g0)) * ldb) * 8
+            if o == rank:      # my rows inside the block: on and below the diagonal
+                li = l0 + (j0 - g0)
+                _dev.call("hydra_chol_update_rect", _addr(A, li, j0), n, _addr(A, li, k_lo), n,
+                          pb_ptr, ldb, g1 - j0, j1 - j0, 0, k_hi - k_lo, st)
+            lb = lay.local_index(g1)      # my rows in later blocks: the whole rectangle
+            if nloc > lb:
+                _dev.call("hydra_chol_update_rect", _addr(A, lb, j0), n, _addr(A, lb, k_lo), n,
+                          pb_ptr, ldb, nloc - lb, j1 - j0, n, k_hi - k_lo, st)
 
-    for k0 in range(0, n, SPW):
-        sp_end = min(k0 + SPW, n)
-        for k in range(k0, sp_end, PBW):
-            pb = min(PBW, n - k)
+    for k0 in range(0, n, SUPER_PANEL):
+        sp_end = min(k0 + SUPER_PANEL, n)
+        for k in range(k0, sp_end, PANEL):
+            pb = min(PANEL, n - k)
             kend = k + pb
-            # diagonal block: every rank contributes the rows it owns
-            D = torch.zeros((pb, pb), dtype=torch.float64, device=dev)
-            d0, d1 = max(r0, k), min(r1, kend)
-            if d1 > d0:
-                D[d0 - k:d1 - k] = A[d0 - r0:d1 - r0, k:kend]
-            comm.allreduce_(D)
-            D = torch.tril(D)
-            D = D + torch.tril(D, -1).T
-            dummy.zero_()
-            _dev.call("hydra_chol_solve", _dev.ptr(D), _dev.ptr(dummy), pb, _dev.ptr(info), st)
+            blk = k // B
+            o, l0 = lay.owner(blk), lay.local_start(blk) + (k - blk * B)
+            lb = lay.local_index(kend)            # my first row below the diagonal block
+            nbelow = nloc - lb
+            # [diagonal block; my rows of the panel below it], contiguous with leading dimension pb
+            if pb == PANEL:
+                P = mine_ext[lb:lb + PANEL + nbelow]
+            else:                                  # the last, narrower panel has no rows below
+                P = torch.empty((pb, pb), dtype=torch.float64, device=dev)
+            if rank == o:
+                P[:pb].copy_(A[l0:l0 + pb, k:kend])
+            if multi:
+                comm.bcast_(P[:pb], root=o)
+            if nbelow > 0:
+                P[pb:].copy_(A[lb:, k:kend])
+            _dev.call("hydra_chol_panel", _dev.ptr(P), pb, pb + nbelow, pb, _dev.ptr(info), st)
             bad |= info
-            L = torch.tril(D)
-            if d1 > d0:
+            if rank == o:
                 # the factor goes below the diagonal only: what is above it stays the operator
                 # (ptsrc_sampler.SystemCache.matvec reads it after the factorisation)
-                blk = A[d0 - r0:d1 - r0, k:kend]
-                low = torch.ones((pb, pb), dtype=torch.bool, device=dev).tril()[d0 - k:d1 - k]
-                blk.copy_(torch.where(low, L[d0 - k:d1 - k], blk))
-            # this rank's rows of the panel below the block: X L^T = P
-            i0 = max(r0, kend)
-            rest = n - kend
-            if r1 > i0:
-                X = mine[i0 - r0:nloc] if rest > 0 else torch.empty((r1 - i0, pb), dtype=torch.float64,
-                                                                    device=dev)
-                torch.linalg.solve_triangular(L.T, A[i0 - r0:, k:kend].contiguous(), upper=True,
-                                              left=False, out=X)
-                A[i0 - r0:, k:kend] = X
-            if rest <= 0:
+                blkv = A[l0:l0 + pb, k:kend]
+                blkv.copy_(torch.where(low[:pb, :pb], P[:pb], blkv))
+            if nbelow > 0:
+                A[lb:, k:kend].copy_(P[pb:])
+            if n - kend <= 0:
                 break
-            # the whole panel, in global row order, on every rank
-            comm.allgather_into_(panel, mine)
+            # the whole panel on every rank (rank o's local row l at o * maxloc + l)
+            if multi:
+                comm.allgather_into_(panel, mine)
             if spanel is not None and n > sp_end:
-                spanel[kend:, k - k0:kend - k0] = panel[kend:]
+                spanel[:, k - k0:kend - k0].copy_(panel)
             # the columns of this super-panel that are still to be factored
-            update(i0, kend, sp_end, k, kend, panel.data_ptr() + kend * PBW * 8, PBW)
+            update(kend, sp_end, k, kend, panel, PANEL)
         if n > sp_end:
             # everything right of the super-panel, once, with K = its width
-            update(max(r0, sp_end), sp_end, n, k0, sp_end, spanel.data_ptr() + sp_end * SPW * 8, SPW)
-    comm.allreduce_(bad, op="max")
+            update(sp_end, n, k0, sp_end, spanel, SUPER_PANEL)
+    if multi:
+        comm.allreduce_(bad, op="max")
     if int(bad.item()) != 0:
         raise np.linalg.LinAlgError("matrix is not positive definite")
     return RowShardedFactor(comm, A, n)

@@ -327,8 +327,9 @@ class SystemCache:
         assert self.A is not None, "SystemCache.solve: no operator (call precompute_mpi(cache=) first)"
         if self.factor is None:
             if self.rows:
-                r0, r1 = self.comm.row_range(self.A.shape[1])
-                self.diag = self.A.diagonal(offset=r0).clone()
+                lay = self.comm.row_layout(self.A.shape[1])
+                rows = self.comm._rows_dev(lay, lay.rank, self.A.device)
+                self.diag = self.A[torch.arange(rows.numel(), device=rows.device), rows].clone()
                 self.factor = linear_solver.factor_dense_rows(self.comm, self.A, overwrite_a=True)
             else:
                 self.diag = self.A.diagonal().clone()
@@ -344,18 +345,23 @@ class SystemCache:
         from the strict upper triangle, its transpose and the saved diagonal, in row blocks)."""
         xd = _dev.f64(x)
         n = self.A.shape[1]
-        r0, r1 = self.comm.row_range(n) if self.rows else (0, n)
-        if self.factor is None or (not self.rows and self.factor.L is not self.A):
-            y = torch.zeros(n, dtype=torch.float64, device=xd.device)
-            y[r0:r1] = self.A @ xd
+        y = torch.zeros(n, dtype=torch.float64, device=xd.device)
+        if self.rows:
+            lay = self.comm.row_layout(n)
+            blocks = [(lay.local_start(b),) + lay.block_range(b) for b in lay.blocks_of()]
+            rows = self.comm._rows_dev(lay, lay.rank, xd.device)
         else:
-            y = torch.zeros(n, dtype=torch.float64, device=xd.device)
-            y[r0:r1] = self.diag * xd[r0:r1]
-            for i0 in range(r0, r1, block):
-                i1 = min(i0 + block, r1)
-                U = torch.triu(self.A[i0 - r0:i1 - r0], diagonal=i0 + 1)
-                y[i0:i1] += U @ xd
-                y += U.T @ xd[i0:i1]
+            blocks, rows = [(0, 0, n)], slice(0, n)
+        if self.factor is None or (not self.rows and self.factor.L is not self.A):
+            y[rows] = self.A @ xd
+        else:
+            y[rows] = self.diag * xd[rows]
+            for l0, g0, g1 in blocks:              # (first local row, global rows [g0, g1))
+                for i0 in range(g0, g1, block):
+                    i1 = min(i0 + block, g1)
+                    U = torch.triu(self.A[l0 + i0 - g0:l0 + i1 - g0], diagonal=i0 + 1)
+                    y[i0:i1] += U @ xd
+                    y += U.T @ xd[i0:i1]
         if self.rows:
             self.comm.allreduce_(y)
         return y
@@ -404,8 +410,8 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
     return value is the full system, as in the reference.
 
     ``shard_rows=True`` (with ``comm``): the sum leaves the operator SHARDED BY ROWS instead --
-    every rank returns its rows ``comm.row_range(Ns)`` of ``A`` (a view of its partial Gram,
-    reduced in place) and the full ``b``; solve with
+    every rank returns its rows ``comm.row_layout(Ns).rows()`` of ``A`` (block-cyclic, see
+    ``_dist.RowLayout``) and the full ``b``; solve with ``linear_solver.solve_dense_rows`` or
     ``linear_solver.cg(None, b, linear_op=linear_solver.RowShardedOperator(comm, A_rows, Ns))``.
     For source counts whose matrix one GPU holds but should not multiply alone (config 5).
 
@@ -499,10 +505,11 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         comm.allreduce_(b)
         if not hit:
             A = comm.reduce_rows_(A)
-            r0, r1 = comm.row_range(ns)
-            if r1 > r0:
-                A.mul_(sigma[None, :]).mul_(sigma[r0:r1, None])
-                A.diagonal(offset=r0).add_(1.0)
+            lay = comm.row_layout(ns)
+            rows = comm._rows_dev(lay, lay.rank, A.device)
+            if rows.numel():
+                A.mul_(sigma[None, :]).mul_(sigma[rows, None])
+                A[torch.arange(rows.numel(), device=A.device), rows] += 1.0
         oa = om_a if myid == 0 else torch.zeros(ns, dtype=torch.float64, device=b.device)
         comm.bcast_(oa, root=0)
         b += oa

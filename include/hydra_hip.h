@@ -380,6 +380,21 @@ int hydra_chol_apply(const double* L, double* b, int n, void* stream);
  * stale).  b == NULL: factor only.  *info_dev = 1 if A is not positive definite.              */
 int hydra_chol_solve_blocked(double* A, double* b, int n, int32_t* info_dev, void* stream);
 
+/* Pieces of the same dense solve (example.py:940-947) for an operator sharded by rows over GPUs
+ * (hydra_amd.linear_solver.factor_dense_rows), each on arrays with an explicit leading dimension:
+ *   hydra_chol_panel : P (nrows x ncols, ld) = a diagonal block (its lower triangle) on top of the
+ *                      rows below it: L11 <- chol(block), rows <- rows L11^-T, by the 32-wide steps
+ *                      of hydra_chol_solve (ncols <= 256 in practice; a multiple of 32 unless nrows
+ *                      == ncols)
+ *   hydra_trsv_block : b <- L^-1 b (transpose = 0) or L^-T b (1) with the n x n lower triangle L
+ *                      (n <= 12288), one diagonal block of the sharded factor
+ *   hydra_gemv_sub   : y[nrows] -= M x[ncols] (transpose = 0) or y[ncols] -= M^T x[nrows] (1) for
+ *                      an nrows x ncols piece M of the factor: the sweeps' off-diagonal part    */
+int hydra_chol_panel(double* P, long long ld, int nrows, int ncols, int32_t* info_dev, void* stream);
+int hydra_trsv_block(const double* L, long long ld, int n, double* b, int transpose, void* stream);
+int hydra_gemv_sub(const double* M, long long ld, int nrows, int ncols, const double* x, double* y,
+                   int transpose, void* stream);
+
 /* The trailing update of that factorisation as a building block for matrices sharded by rows over
  * GPUs (hydra_amd.linear_solver.solve_dense_rows; the same dense solve, example.py:940-947):
  *   C[i][j] -= sum_{k < kdim} PA[i][k] PB[j][k]   for i < mrows, j < ncols, j <= i + diag

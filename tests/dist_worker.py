@@ -70,18 +70,25 @@ def case_comm(comm):
     assert [float(p.item()) for p in parts] == [float(r) for r in range(size)]
     obj = comm.bcast({"k": rank}, root=0)
     assert obj == {"k": 0}
-    # row sharding of a dense operator: block row k of the sum lands on rank k, vectors come back
-    # whole (n not a multiple of the world size; a rank may own no row at all)
-    for n in (7, size - 1 if size > 1 else 1):
-        ranges = [comm.row_range(n, k) for k in range(size)]
-        assert ranges[0][0] == 0 and ranges[-1][1] == n
-        assert all(ranges[k][1] == ranges[k + 1][0] for k in range(size - 1))
+    # row sharding of a dense operator: block-cyclic rows (256-row blocks at these sizes), every
+    # block of the sum lands on its owner, vectors come back whole (a ragged last block; a rank
+    # may own no row at all)
+    for n in (7, 300, 256 * size + 40, 256 * (2 * size + 1)):
+        lay = comm.row_layout(n)
+        allrows = np.concatenate([lay.rows(k) for k in range(size)])
+        assert np.array_equal(np.sort(allrows), np.arange(n)) and lay.block % 256 == 0
+        assert all(lay.owner(b) == b % size for b in range(lay.nblocks))
+        mine_rows = lay.rows()
+        assert mine_rows.size == lay.nloc() and np.all(np.diff(mine_rows) > 0)
+        for b in lay.blocks_of():
+            g0, g1 = lay.block_range(b)
+            assert np.array_equal(mine_rows[lay.local_start(b):lay.local_start(b) + g1 - g0], np.arange(g0, g1))
+        assert lay.local_index(n) == lay.nloc() and lay.local_index(0) == 0
         A = torch.arange(n * 3, dtype=torch.float64).reshape(n, 3) * (rank + 1)
         mine = comm.reduce_rows_(A)
-        r0, r1 = comm.row_range(n)
-        want = torch.arange(n * 3, dtype=torch.float64).reshape(n, 3)[r0:r1] * sum(range(1, size + 1))
+        want = torch.arange(n * 3, dtype=torch.float64).reshape(n, 3)[mine_rows] * sum(range(1, size + 1))
         assert mine.shape == want.shape and torch.equal(mine, want)
-        full = comm.allgather_rows(torch.arange(r0, r1, dtype=torch.float64), n)
+        full = comm.allgather_rows(torch.as_tensor(mine_rows, dtype=torch.float64), n)
         assert torch.equal(full, torch.arange(n, dtype=torch.float64))
     comm.barrier()
 
@@ -247,9 +254,9 @@ def case_rowshard(comm):
         torch.as_tensor(p["data"][:, fidx], device=dev), p["inv_noise"][:, fidx], p["gains"][:, fidx],
         p["prior"], omega_n=p["om_n"][:, fidx], omega_a=p["om_a"] if rank == 0 else None,
         shard_rows=True)
-    r0, r1 = comm.row_range(ns)
-    assert tuple(A_rows.shape) == (r1 - r0, ns)
-    ea = np.max(np.abs(A_rows.cpu().numpy() - A1[r0:r1])) / np.max(np.abs(A1))
+    myrows = comm.row_layout(ns).rows()
+    assert tuple(A_rows.shape) == (myrows.size, ns)
+    ea = (np.max(np.abs(A_rows.cpu().numpy() - A1[myrows])) / np.max(np.abs(A1))) if myrows.size else 0.0
     eb = np.max(np.abs(b2.cpu().numpy() - b1)) / np.max(np.abs(b1))
     assert ea < 1e-12 and eb < 1e-12, (ea, eb)
     op = hy.linear_solver.RowShardedOperator(comm, A_rows, ns)
@@ -570,18 +577,31 @@ def case_cholrows(comm):
         A = B @ B.T / n + np.eye(n)
         b = rng.randn(n)
         want = np.linalg.solve(A, b)
-        r0, r1 = comm.row_range(n)
-        rows = torch.as_tensor(A[r0:r1], device=dev).contiguous()
+        mine = comm.row_layout(n).rows()
+        rows = torch.as_tensor(A[mine], device=dev).contiguous()
         x = linear_solver.solve_dense_rows(comm, rows, torch.as_tensor(b, device=dev))
         got = x.cpu().numpy()
         assert np.max(np.abs(got - want)) <= 1e-11 * np.max(np.abs(want)), (n, np.max(np.abs(got - want)))
-        assert torch.equal(rows, torch.as_tensor(A[r0:r1], device=dev))      # input untouched
+        assert torch.equal(rows, torch.as_tensor(A[mine], device=dev))      # input untouched
+        # factor once, solve twice; what lies above the diagonal is still the operator
+        fac = linear_solver.factor_dense_rows(comm, rows)
+        for seed in (1, 2):
+            b2 = np.random.RandomState(seed).randn(n)
+            got2 = fac.solve(torch.as_tensor(b2, device=dev)).cpu().numpy()
+            want2 = np.linalg.solve(A, b2)
+            assert np.max(np.abs(got2 - want2)) <= 1e-11 * np.max(np.abs(want2)), (n, seed)
+        if mine.size:
+            up = np.triu(np.ones((n, n), dtype=bool), 1)[mine]
+            assert np.array_equal(fac.A.cpu().numpy()[up], A[mine][up])
+            L = np.linalg.cholesky(A)
+            lo = np.tril(np.ones((n, n), dtype=bool))[mine]
+            assert np.max(np.abs(fac.A.cpu().numpy()[lo] - L[mine][lo])) <= 1e-11 * np.max(np.abs(L))
     linear_solver.SUPER_PANEL = 2048
     # not positive definite: every rank raises
     A = -np.eye(300)
-    r0, r1 = comm.row_range(300)
+    mine = comm.row_layout(300).rows()
     try:
-        linear_solver.solve_dense_rows(comm, torch.as_tensor(A[r0:r1], device=dev).contiguous(),
+        linear_solver.solve_dense_rows(comm, torch.as_tensor(A[mine], device=dev).contiguous(),
                                        torch.ones(300, dtype=torch.float64, device=dev))
         raise AssertionError("no error for an indefinite matrix")
     except np.linalg.LinAlgError:

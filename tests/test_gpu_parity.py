@@ -985,6 +985,33 @@ def test_tiled_sh_projection_matches_untiled_kernel(hy):
     assert torch.equal(out, tiled)
 
 
+def test_tiled_sh_projection_matches_oracle_on_full_antenna_blocks(hy, orc):
+    """The tiled projection kernel (16-antenna blocks) against the ORACLE on whole blocks: all 666
+    cross pairs of a 37-antenna array = block pairs (0,0), (0,1), (0,2), (1,1), (1,2), (2,2) with
+    two full 16-antenna blocks and a partial one, two channels x three LSTs (one with most of
+    the sky set), lmax 12 (169 real modes: a full and a partial 128-mode tile), spectral factor.
+    (test_tiled_sh_projection_matches_untiled_kernel compares two kernels with each other; the
+    full-size check of config 3 reaches the oracle on a 5-antenna sub-array only.)"""
+    ant_pos = hy.utils.build_hex_array(hex_spec=(4, 7), d=14.6)
+    nant = len(ant_pos)
+    freqs, lsts = np.array([100.0, 117.0]), np.array([0.2, 1.7, 4.0])
+    lmax, nside = 12, 8
+    bh = [hy.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    bo = [orc.beams.GaussianBeam(diameter=14.0) for _ in ant_pos]
+    R_ref, _, ell_ref, m_ref = orc.sh.vis_proj_operator_no_rot(freqs, lsts, bo, ant_pos, lmax, nside,
+                                                               latitude=LAT, ref_freq=100.0,
+                                                               spectral_idx=-2.7)
+    from hydra_amd import vis_simulator as vs
+    V = vs.sh_voltages(nside, ant_pos, freqs * 1e6, lsts, bh, LAT)
+    assert getattr(V, "hydra_pixidx", None) is not None          # the tiled kernel's pixel lists
+    R, ell, m = hy.sh_sampler.vis_proj_operator_no_rot(freqs, lsts, bh, ant_pos, lmax, nside,
+                                                       latitude=LAT, ref_freq=100.0,
+                                                       spectral_idx=-2.7, cross_only=True)
+    assert R.shape == R_ref.shape == (nant * (nant - 1) // 2 * 2 * 3, (lmax + 1) ** 2)
+    assert np.array_equal(ell, ell_ref) and np.array_equal(m, m_ref)
+    assert operr(R, R_ref) < OP_TOL
+
+
 def test_gain_operator_with_autos_and_repeated_pairs(hy):
     """Pair lists with auto-correlations (count twice in A^H A) go through the LDS-tiled kernel,
     lists that repeat a pair fall back to the adjacency kernel; both against the oracle."""

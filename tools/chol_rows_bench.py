@@ -16,12 +16,13 @@ os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
 dist.init_process_group(backend=os.environ.get("HYDRA_DIST_BACKEND", "nccl"))
 comm = _dist.Comm()
 rank, size = comm.Get_rank(), comm.Get_size()
-for n in [int(a) for a in sys.argv[1:]] or [16384, 32768]:
-    r0, r1 = comm.row_range(n)
+for n in [int(a) for a in sys.argv[1:] if not a.startswith("--")] or [16384, 32768]:
+    lay = comm.row_layout(n)
+    mine = torch.as_tensor(lay.rows(), device="cuda")
     g = torch.Generator(device="cuda").manual_seed(n)
     B = torch.randn(n, 512, dtype=torch.float64, device="cuda", generator=g)
-    rows = (B[r0:r1] @ B.T) / 512
-    rows[:, r0:r1] += torch.eye(r1 - r0, dtype=torch.float64, device="cuda")
+    rows = (B[mine] @ B.T) / 512
+    rows[torch.arange(mine.numel(), device="cuda"), mine] += 1.0
     b = torch.randn(n, dtype=torch.float64, device="cuda", generator=g)
     ref = rows.clone()
     torch.cuda.synchronize(); comm.barrier()
@@ -29,12 +30,25 @@ for n in [int(a) for a in sys.argv[1:]] or [16384, 32768]:
     x = linear_solver.solve_dense_rows(comm, rows, b, overwrite_a=True)
     torch.cuda.synchronize(); comm.barrier()
     dt = time.perf_counter() - t0
-    res = ref @ x - b[r0:r1]
+    res = ref @ x - b[mine]
     r2 = torch.sum(res * res).reshape(1)
     comm.allreduce_(r2)
     if rank == 0:
         fl = n ** 3 / 3
         print(f"n={n} ranks={size}: {dt*1e3:.1f} ms = {fl/dt/1e12:.1f} TFLOP/s, rel residual "
               f"{float(torch.sqrt(r2) / torch.linalg.norm(b)):.2e}", flush=True)
-    del rows, ref, B
+    del rows, ref
+    if size == 1 and "--compare" in sys.argv:      # the in-place one-GPU routine on the same matrix
+        A = (B @ B.T) / 512
+        A.diagonal().add_(1.0)
+        b1 = b.clone()
+        torch.cuda.synchronize()
+        t0 = time.perf_counter()
+        linear_solver.solve_dense(A, b1, overwrite_a=True)
+        torch.cuda.synchronize()
+        d1 = time.perf_counter() - t0
+        print(f"n={n} one-GPU in-place routine: {d1*1e3:.1f} ms; row-sharded form on one rank "
+              f"{dt / d1:.2f} x", flush=True)
+        del A
+    del B
 dist.destroy_process_group()
