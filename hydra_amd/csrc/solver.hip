@@ -593,7 +593,14 @@ int hydra_unpack_lower(const double* packed, int n, double* A, void* stream) {
   return HYDRA_OK;
 }
 
-int hydra_symv_static_max_n(void) { return SYMV_STATIC_MAX_N; }
+// Also the set-up call: looks up the scratch array's address on the CURRENT device (a symbol lookup,
+// possibly a module load -- not a stream operation), so that hydra_symv_static itself is nothing
+// but two kernel launches afterwards and may run under HIP graph capture.
+int hydra_symv_static_max_n(void) {
+  double* p = nullptr;
+  (void)scratch_ptr_for_current_device(&p);      // a failure is reported by hydra_symv_static
+  return SYMV_STATIC_MAX_N;
+}
 
 int hydra_symv_static(const double* A, int n, const double* x, double* y, int accumulate,
                       void* stream) {

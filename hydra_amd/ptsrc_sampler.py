@@ -154,7 +154,10 @@ class FactoredProj:
         weight w_ref[f,t], idx their sorted flat indices; ("general",) otherwise.
         The analysis reads one counter back to the host, so it is done once per weight tensor and
         cached (key: storage address + torch's in-place version counter, the tensor kept alive);
-        the Gibbs loop passes the same inv_noise_var every iteration (example.py:878-889)."""
+        the Gibbs loop passes the same inv_noise_var every iteration (example.py:878-889).
+        The version counter only sees torch operations: a weight tensor rewritten through its raw
+        pointer (a kernel of one's own, this package's C ABI) must be followed by
+        ``invalidate_noise_plan()``, or be passed as a new tensor."""
         nf, nt, nant, ns = self.V.shape
         nbl = self.shape[0]
         key = (inv_noise.data_ptr(), inv_noise._version, tuple(inv_noise.shape))
@@ -177,6 +180,11 @@ class FactoredProj:
             plan = ("general",)
         self._plan_cache = (key, inv_noise, plan)
         return plan
+
+    def invalidate_noise_plan(self):
+        """Forget the cached analysis of the noise weights (see ``_noise_plan``)."""
+        self.__dict__.pop("_plan_cache", None)
+        self.__dict__.pop("_chan_plan_cache", None)
 
     def channel_plans(self, inv_noise):
         """``_noise_plan`` of every frequency channel taken alone (for ``channel(j).gram(...,

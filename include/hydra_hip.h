@@ -328,7 +328,11 @@ int hydra_unpack_lower(const double* packed, int n, double* A, void* stream);
  * hipMalloc.  n <= hydra_symv_static_max_n() (8192), larger n is rejected with HYDRA_ERR_ARG.
  * Same kernels, same summation order and bit-identical y as hydra_symv_batched(A, n, 1, ...).
  * All calls on one GPU share that GPU's array: calls that overlap in time on one GPU (different
- * streams or threads) race; calls on one stream are ordered and safe.                        */
+ * streams or threads) race; calls on one stream are ordered and safe.
+ * hydra_symv_static_max_n() is also the SET-UP call: it looks up the array's address on the current
+ * device (a symbol lookup, not a stream operation).  Call it once per device before the first
+ * hydra_symv_static that runs under graph capture; after it hydra_symv_static is two kernel
+ * launches and nothing else (without it the first call on a device does the lookup itself).  */
 int hydra_symv_static_max_n(void);
 int hydra_symv_static(const double* A, int n, const double* x, double* y, int accumulate,
                       void* stream);

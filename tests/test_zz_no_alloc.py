@@ -59,3 +59,33 @@ def test_static_symv_rejects_sizes_beyond_the_scratch():
     with pytest.raises(_lib.HydraError, match="exceeds the static scratch"):
         _dev.call("hydra_symv_static", _dev.ptr(buf), n, _dev.ptr(buf), _dev.ptr(buf), 0,
                   _dev.stream_ptr())
+
+
+def test_static_symv_replays_from_a_captured_graph():
+    """The callers the entry point is for: under HIP graph capture nothing may allocate or look
+    symbols up.  After the set-up call (hydra_symv_static_max_n resolves the scratch address on
+    this device) a call is two kernel launches, which a stream capture records and a graph
+    replays -- with new contents in the same buffers -- bit for bit like the workspace form."""
+    assert _lib.query("hydra_symv_static_max_n") == 8192          # set-up, outside the capture
+    n = 1500
+    A, x = _sym(n, 11)
+    y = torch.zeros(n, dtype=torch.float64, device="cuda")
+    _static(A, x, 0, y)                                           # (warm: kernels loaded)
+    torch.cuda.synchronize()
+    graph = torch.cuda.CUDAGraph()
+    side = torch.cuda.Stream()
+    side.wait_stream(torch.cuda.current_stream())
+    with torch.cuda.stream(side):
+        with torch.cuda.graph(graph, stream=side):
+            _dev.call("hydra_symv_static", _dev.ptr(A), n, _dev.ptr(x), _dev.ptr(y), 0,
+                      _dev.stream_ptr())
+    torch.cuda.current_stream().wait_stream(side)
+    for seed in (12, 13):                                          # new inputs, same buffers
+        A2, x2 = _sym(n, seed)
+        A.copy_(A2)
+        x.copy_(x2)
+        y.fill_(float("nan"))
+        graph.replay()
+        torch.cuda.synchronize()
+        want = _batched(A, x, 0, torch.zeros_like(y))
+        assert torch.equal(y, want), float((y - want).abs().max())
