@@ -14,6 +14,8 @@ the host only reads the flag every ``check_every`` iterations.
 keep the reference's 2-D block layout over ranks (linear_solver.py:11-375) on
 ``hydra_amd._dist.Comm`` (torch.distributed: RCCL on GPUs, gloo on CPUs).
 """
+import ctypes
+
 import numpy as np
 import torch
 
@@ -478,7 +480,9 @@ def factor_dense_rows(comm, A_rows, overwrite_a=False, n=None):
     the matrix right of a SUPER-panel of 2048 columns is updated once, with K = 2048, on the FP64
     matrix cores (``hydra_chol_update_rect``: one round trip of C per 2048 columns instead of per
     256); inside the super-panel the columns still to be factored take a rank-256 update from each
-    finished panel.  With block-cyclic rows every rank's share of the rows below the current column
+    finished panel.  Look-ahead: of that big update the columns of the next super-panel are done
+    first and the rest runs on a second stream, so the next super-panel's chain of short panel
+    kernels, broadcasts and all-gathers is hidden under it.  With block-cyclic rows every rank's share of the rows below the current column
     is the same at every stage (contiguous blocks left the last rank 2 - 1/size times the mean
     work).  n must be even.  Raises ``np.linalg.LinAlgError`` if A is not positive definite."""
     A = _dev.f64(A_rows)
@@ -499,33 +503,46 @@ def factor_dense_rows(comm, A_rows, overwrite_a=False, n=None):
     mine_ext = torch.zeros((PANEL + maxloc, PANEL), dtype=torch.float64, device=dev)
     mine = mine_ext[PANEL:]
     panel = torch.empty((size * maxloc, PANEL), dtype=torch.float64, device=dev) if multi else mine
-    spanel = torch.empty((size * maxloc, SUPER_PANEL), dtype=torch.float64, device=dev) \
-        if n > SUPER_PANEL else None
+    # two gathered super-panels: the matrix far to the right is still taking the last one's update
+    # (on the side stream) while the next one is being filled
+    spanels = [torch.empty((size * maxloc, SUPER_PANEL), dtype=torch.float64, device=dev)
+               for _ in range(2 if n > 2 * SUPER_PANEL else 1)] if n > SUPER_PANEL else None
     low = torch.ones((PANEL, PANEL), dtype=torch.bool, device=dev).tril()
+    main = torch.cuda.current_stream(dev)
+    side = [torch.cuda.Stream(dev), torch.cuda.Stream(dev)] if n > 2 * SUPER_PANEL else None
 
-    def update(c0, c1, k_lo, k_hi, src, ldb):
+    def update(c0, c1, k_lo, k_hi, src, ldb, streams=None):
         """My rows below column c0 of columns [c0, c1) take the rank-(k_hi - k_lo) update
         C[i][j] -= sum_k A[i][k] L[j][k], k in [k_lo, k_hi): PA = my rows, PB = the gathered rows
         of ``src`` (leading dimension ldb; rank o's local row l at o * maxloc + l), one column
         block at a time -- the rows of a block sit together in ``src``."""
         if c1 <= c0 or nloc == 0:
             return
-        for cb in range(c0 // B, (c1 - 1) // B + 1):
+        for it, cb in enumerate(range(c0 // B, (c1 - 1) // B + 1)):
+            # column blocks write different columns: on two streams in turn, so that the last,
+            # partly filled round of workgroups of one call runs beside the first of the next
+            st = _dev.stream_ptr() if streams is None else \
+                ctypes.c_void_p(streams[it % len(streams)].cuda_stream)
             g0, g1 = lay.block_range(cb)
             j0, j1 = max(c0, g0), min(c1, g1)
             o, l0 = lay.owner(cb), lay.local_start(cb)
             pb_ptr = src.data_ptr() + ((o * maxloc + l0 + (j0 - g0)) * ldb) * 8
-            if o == rank:      # my rows inside the block: on and below the diagonal
+            if o == rank:
+                # my rows from the diagonal on: inside the block those left of column j <= row,
+                # and the rows of my later blocks follow in local order, where that holds for
+                # every column -- one trapezoid
                 li = l0 + (j0 - g0)
                 _dev.call("hydra_chol_update_rect", _addr(A, li, j0), n, _addr(A, li, k_lo), n,
-                          pb_ptr, ldb, g1 - j0, j1 - j0, 0, k_hi - k_lo, st)
-            lb = lay.local_index(g1)      # my rows in later blocks: the whole rectangle
-            if nloc > lb:
-                _dev.call("hydra_chol_update_rect", _addr(A, lb, j0), n, _addr(A, lb, k_lo), n,
-                          pb_ptr, ldb, nloc - lb, j1 - j0, n, k_hi - k_lo, st)
+                          pb_ptr, ldb, nloc - li, j1 - j0, 0, k_hi - k_lo, st)
+            else:              # my rows in later blocks: the whole rectangle
+                lb = lay.local_index(g1)
+                if nloc > lb:
+                    _dev.call("hydra_chol_update_rect", _addr(A, lb, j0), n, _addr(A, lb, k_lo), n,
+                              pb_ptr, ldb, nloc - lb, j1 - j0, n, k_hi - k_lo, st)
 
-    for k0 in range(0, n, SUPER_PANEL):
+    for isp, k0 in enumerate(range(0, n, SUPER_PANEL)):
         sp_end = min(k0 + SUPER_PANEL, n)
+        spanel = spanels[isp % len(spanels)] if spanels is not None else None
         for k in range(k0, sp_end, PANEL):
             pb = min(PANEL, n - k)
             kend = k + pb
@@ -563,8 +580,21 @@ def factor_dense_rows(comm, A_rows, overwrite_a=False, n=None):
             # the columns of this super-panel that are still to be factored
             update(kend, sp_end, k, kend, panel, PANEL)
         if n > sp_end:
-            # everything right of the super-panel, once, with K = its width
-            update(sp_end, n, k0, sp_end, spanel, SUPER_PANEL)
+            # everything right of the super-panel, once, with K = its width -- the columns of the
+            # NEXT super-panel first, the rest on the side stream: the next super-panel's panel
+            # steps, broadcasts and all-gathers (short kernels and transfers in a dependent chain)
+            # then run under this update instead of after it.  Same kernels on the same elements
+            # in the same order, so the factor does not depend on the split.
+            nxt = min(sp_end + SUPER_PANEL, n)
+            for sd in side or ():
+                main.wait_stream(sd)         # the columns [sp_end, nxt) have taken the last update
+            update(sp_end, nxt, k0, sp_end, spanel, SUPER_PANEL)
+            if n > nxt:
+                for sd in side or ():
+                    sd.wait_stream(main)     # the gathered super-panel is complete
+                update(nxt, n, k0, sp_end, spanel, SUPER_PANEL, streams=side)
+    for sd in side or ():
+        main.wait_stream(sd)
     if multi:
         comm.allreduce_(bad, op="max")
     if int(bad.item()) != 0:

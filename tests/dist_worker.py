@@ -568,9 +568,11 @@ def case_cholrows(comm):
     rank, size = comm.Get_rank(), comm.Get_size()
     dev = torch.device("cuda")
     # (n, super-panel width): the default 2048 on both sides of its edge, and narrow super-panels
-    # so that several trailing updates with K = 512 follow one another at a small size
+    # so that several trailing updates with K = 512 follow one another at a small size (beyond two
+    # super-panels the far part of an update runs on a side stream under the next panels, and the
+    # two gathered super-panel buffers take turns: 2100 / 512 reuses the first one)
     for n, spw in ((2, 2048), (254, 2048), (256, 2048), (258, 2048), (700, 2048), (1026, 2048),
-                   (1026, 512), (1300, 512), (2306, 2048)):
+                   (1026, 512), (1300, 512), (2100, 512), (2306, 2048)):
         linear_solver.SUPER_PANEL = spw
         rng = np.random.RandomState(n)
         B = rng.randn(n, n + 5)

@@ -13,6 +13,8 @@ from hydra_amd import _dev, _dist, linear_solver
 
 torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")) % torch.cuda.device_count())
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+for key, val in (("RANK", "0"), ("WORLD_SIZE", "1"), ("MASTER_PORT", "29531")):   # started bare: one rank
+    os.environ.setdefault(key, val)
 dist.init_process_group(backend=os.environ.get("HYDRA_DIST_BACKEND", "nccl"))
 comm = _dist.Comm()
 rank, size = comm.Get_rank(), comm.Get_size()
