@@ -497,58 +497,258 @@ chol_syrk_mfma_kernel(double* __restrict__ C, long long ldc, const double* __res
       }
 }
 
-// Triangular solves for large n, one 256-wide panel at a time (right-looking both ways, so no
-// sum crosses workgroups): the diagonal block is solved by trsv_fused_kernel on that block, then
-//   forward : b[r] -= L[r, k:k+256] . y_k   for the rows r below the panel (one wave per row,
+// Triangular solves for large n, one 256-wide panel at a time, ONE launch per panel.  A sweep is a
+// dependent chain (n = 100 000: 391 panels), so what a link costs is what matters: with the diagonal
+// block's substitution and the update of the rest of the vector as two launches a panel took 52 us
+// (30 + 22) at that size, most of the 30 being first-touch latencies of L, one per 32-row step.  Now
+// launch p has a SOLVING workgroup -- it takes the previous panel's solution out of panel p's own 256
+// entries (a 256 x 256 piece of L) and then solves the diagonal block, the loads of each 32-row step
+// issued one step ahead -- beside the workgroups that take the previous panel's solution out of
+// everything further on:
+//   forward : b[r] -= L[r, k-256:k] . y_prev   for the rows r beyond panel p (one wave per 4 rows,
 //             4 columns per lane: a row of the panel is 2 KiB contiguous);
-//   backward: b[c] -= sum_r L[k+r, c] x_k[r] for the columns c left of the block (one thread per
-//             column, coalesced along the rows of L).
-// Both stream their part of L once: 4 n^2 bytes per sweep, HBM-bound.
-__global__ void __launch_bounds__(256)
-chol_fwd_update_kernel(const double* __restrict__ A, size_t ld, int n, int k, double* __restrict__ b) {
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const f64x2* yk = reinterpret_cast<const f64x2*>(b + k);
-  const f64x2 y0 = yk[2 * lane], y1 = yk[2 * lane + 1];
-  const int r_begin = k + PB;
-  for (int r = r_begin + (blockIdx.x * 4 + wave) * 4; r < n; r += gridDim.x * 16) {
-    f64x2 v[4][2];
+//   backward: b[c] -= sum_r L[k+256+r, c] x_next[r] for the columns c left of panel p (a workgroup per
+//             256 columns, its four quarters take 64 rows each: coalesced along the rows of L).
+// Right-looking both ways, so no sum crosses workgroups; fixed order.  Each sweep streams L once:
+// 4 n^2 bytes, HBM-bound.
+constexpr int SWT = 1024;          // threads of a sweep workgroup (the 32 x 32 layout of a substitution step)
+static_assert(SWT == NB * NB && PB == 256, "sweep kernels: 32 x 32 threads, 256-wide panels");
+
+struct SweepShared {
+  double l[NB][NB + 1];
+  double part[NB][NB + 1];
+  double dinv[NB];
+  double bl[PB + 2];               // the panel's entries of the vector; bl[PB] stays 0.0 (masked operands)
+  double red[4][PB];               // backward: the four row quarters' sums per column
+};
+
+// One 32-row step of the solve with the nb x nb (nb <= 256) lower-triangular block D (leading
+// dimension ld) against sh.bl -- SWEEP 0: L y = b top down, 1: L^T x = y bottom up -- at rows k.
+// All SWT threads; thread (ta, tc) = (tid / 32, tid % 32).  `a` is this thread's entry of the step's
+// 32 x 32 diagonal block and rv its (at most 7) values of L outside it; the next step's are loaded
+// into an / rvn before anything here waits (two register sets that the caller swaps: copying one set
+// into the other would wait for the loads at once).
+template <int SWEEP>
+__device__ __forceinline__ void sweep_step(const double* __restrict__ D, size_t ld, int nb, int k,
+                                           bool more, SweepShared& sh, int tid, double a,
+                                           const double (&rv)[7], double& an, double (&rvn)[7]) {
+  const int ta = tid / NB, tc = tid % NB;
+  const int w = min(NB, nb - k);
+  // the step's diagonal block without its diagonal (whose reciprocals go to dinv): the substitution
+  // factors below are then zero wherever an entry is closed, with nothing to test
+  sh.l[ta][tc] = (ta < w && tc < ta) ? a : 0.0;
+  if (ta == tc) sh.dinv[ta] = (ta < w) ? 1.0 / a : 1.0;
+  if (more) {
+    const int kn = SWEEP ? k - NB : k + NB;
+    an = D[(size_t)min(kn + ta, nb - 1) * ld + min(kn + tc, nb - 1)];
+    if (SWEEP == 0) {              // row kn + ta, columns tc + 32 u (used where < kn)
+      const double* row = D + (size_t)min(kn + ta, nb - 1) * ld;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      const f64x2* row = reinterpret_cast<const f64x2*>(A + (size_t)min(r + u, n - 1) * ld + k);
-      v[u][0] = row[2 * lane];
-      v[u][1] = row[2 * lane + 1];
+      for (int u = 0; u < 7; ++u) rvn[u] = row[min(tc + u * NB, nb - 1)];
+    } else {                       // column kn + tc, rows kn + 32 + ta + 32 u (used where < nb)
+      const double* col = D + min(kn + tc, nb - 1);
+#pragma unroll
+      for (int u = 0; u < 7; ++u) rvn[u] = col[(size_t)min(kn + NB + ta + u * NB, nb - 1) * ld];
     }
+  }
+  // this thread's part of (rows of L) . (entries solved so far); where a product does not count its
+  // vector operand is read from the zero slot -- a test on the product became a branch around an
+  // LDS read with a wait of its own, seven times
+  double s0 = 0.0, s1 = 0.0;
 #pragma unroll
-    for (int u = 0; u < 4; ++u) {
-      double s = (v[u][0].x * y0.x + v[u][0].y * y0.y) + (v[u][1].x * y1.x + v[u][1].y * y1.y);
-      s = wave_sum(s);
-      if (lane == 0 && r + u < n) b[r + u] -= s;
+  for (int u = 0; u < 7; ++u) {
+    const int i = SWEEP ? k + NB + ta + u * NB : tc + u * NB;
+    const bool in = SWEEP ? i < nb : i < k;
+    const double t = rv[u] * sh.bl[in ? i : PB];
+    if (u & 1) s1 += t; else s0 += t;
+  }
+  if (SWEEP == 0) sh.part[tc][ta] = s0 + s1;   // part[q][i]: partial q of the step's entry i
+  else            sh.part[ta][tc] = s0 + s1;
+  __syncthreads();
+  if (tid < 64) {                  // lane i owns entry i of the step (lanes 32-63 mirror 0-31)
+    // The substitution is a chain of 32 dependent steps, so a step is kept to a lane broadcast and
+    // one multiply-add: z_i is the running numerator b_i - sum_j l_ij y_j, step c subtracts
+    // (l_ic / l_cc) z_c from the entries still open -- the factor is formed ahead of the chain and
+    // is zero for the entries that are done -- and y = z / l_ii at the end.
+    const int lane = tid & (NB - 1);
+    double z = sh.bl[lane < w ? k + lane : PB];
+    double p0 = 0.0, p1 = 0.0, p2 = 0.0, p3 = 0.0;
+#pragma unroll
+    for (int q = 0; q < NB; q += 4) {
+      p0 += sh.part[q][lane];
+      p1 += sh.part[q + 1][lane];
+      p2 += sh.part[q + 2][lane];
+      p3 += sh.part[q + 3][lane];
+    }
+    z -= (p0 + p1) + (p2 + p3);
+    // (the factors eight at a time: all 32 of them beside the prefetched values of L spill)
+#pragma unroll
+    for (int h = 0; h < NB; h += 8) {
+      const int c0 = SWEEP ? NB - 8 - h : h;
+      double m[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        const int c = c0 + u;
+        m[u] = (SWEEP ? sh.l[c][lane] : sh.l[lane][c]) * sh.dinv[c];
+      }
+      if (SWEEP == 0) {
+#pragma unroll
+        for (int u = 0; u < 8; ++u) z -= m[u] * readlane_f64(z, c0 + u);
+      } else {
+#pragma unroll
+        for (int u = 7; u >= 0; --u) z -= m[u] * readlane_f64(z, c0 + u);
+      }
+    }
+    if (tid < w) sh.bl[k + tid] = z * sh.dinv[tid];
+  }
+  __syncthreads();
+}
+
+// The whole block: sh.bl[0:nb] in, solution out; sh.bl[PB] must hold 0.0.
+template <int SWEEP>
+__device__ __forceinline__ void sweep_block_solve(const double* __restrict__ D, size_t ld, int nb,
+                                                  SweepShared& sh, int tid) {
+  const int ta = tid / NB, tc = tid % NB;
+  const int nsteps = (nb + NB - 1) / NB;
+  const int dk = SWEEP ? -NB : NB;
+  int k = SWEEP ? (nsteps - 1) * NB : 0;
+  double a0 = D[(size_t)min(k + ta, nb - 1) * ld + min(k + tc, nb - 1)], a1 = 0.0, rv0[7], rv1[7];
+  if (SWEEP == 0) {                // the first step has nothing outside its diagonal block; the last
+#pragma unroll                     // step of the backward sweep neither
+    for (int u = 0; u < 7; ++u) rv0[u] = 0.0;
+  } else {
+#pragma unroll
+    for (int u = 0; u < 7; ++u) rv0[u] = 0.0;
+  }
+#pragma unroll 1
+  for (int it = 0; it < nsteps; it += 2) {
+    sweep_step<SWEEP>(D, ld, nb, k, it + 1 < nsteps, sh, tid, a0, rv0, a1, rv1);
+    k += dk;
+    if (it + 1 < nsteps) {
+      sweep_step<SWEEP>(D, ld, nb, k, it + 2 < nsteps, sh, tid, a1, rv1, a0, rv0);
+      k += dk;
     }
   }
 }
 
-__global__ void __launch_bounds__(256)
-chol_bwd_update_kernel(const double* __restrict__ A, size_t ld, int k, int nb, double* __restrict__ b) {
-  __shared__ double xk[PB];
-  for (int i = threadIdx.x; i < nb; i += 256) xk[i] = b[k + i];
-  __syncthreads();
-  const int c = blockIdx.x * 256 + threadIdx.x;
-  const int cc = min(c, k - 1);
-  const double* col = A + (size_t)k * ld + cc;
-  double s0 = 0.0, s1 = 0.0;
-  int r = 0;
-  for (; r + 8 <= nb; r += 8) {
-    double v[8];
+// Forward, panel p at rows / columns k = 256 p (pb of them; only the last panel is narrower).
+// Workgroup 0 solves, the others update the rows beyond the panel with the previous panel's solution.
+__global__ void __launch_bounds__(SWT)
+chol_fwd_step_kernel(const double* __restrict__ A, size_t ld, int n, int k, double* __restrict__ b) {
+  __shared__ SweepShared sh;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int pb = min(PB, n - k);
+  f64x2 y0 = {0.0, 0.0}, y1 = {0.0, 0.0};
+  if (k > 0) {
+    const f64x2* yp = reinterpret_cast<const f64x2*>(b + k - PB);
+    y0 = yp[2 * lane];
+    y1 = yp[2 * lane + 1];
+  }
+  // NR rows (from r, clamped below r_end) of the previous panel's 256 columns against its solution:
+  // b[row] minus the product, in every lane.  All loads first, then the NR wave sums side by side
+  // (one after the other each of them is six dependent lane exchanges).
+  auto rows = [&](int r, int r_end, auto& out) {
+    constexpr int NR = sizeof(out) / sizeof(double);
+    f64x2 v[NR][2];
+    double bq[NR];
 #pragma unroll
-    for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(r + u) * ld];
+    for (int u = 0; u < NR; ++u) {
+      const int rr = min(r + u, r_end - 1);
+      const f64x2* row = reinterpret_cast<const f64x2*>(A + (size_t)rr * ld + (k - PB));
+      v[u][0] = row[2 * lane];
+      v[u][1] = row[2 * lane + 1];
+      bq[u] = b[rr];
+    }
+    // (b rides in lane 0's term of the sum: used only in the store at the end, its load moved
+    // there, behind the reductions and under a wait of its own)
+    double t[NR];
 #pragma unroll
-    for (int u = 0; u < 8; u += 2) {
-      s0 += v[u] * xk[r + u];
-      s1 += v[u + 1] * xk[r + u + 1];
+    for (int u = 0; u < NR; ++u)
+      t[u] = ((v[u][0].x * y0.x + v[u][0].y * y0.y) + (v[u][1].x * y1.x + v[u][1].y * y1.y)) -
+             (lane == 0 ? bq[u] : 0.0);
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1)
+#pragma unroll
+      for (int u = 0; u < NR; ++u) t[u] += __shfl_down(t[u], off, 64);
+#pragma unroll
+    for (int u = 0; u < NR; ++u) out[u] = -t[u];
+  };
+  if (tid == 0) sh.bl[PB] = 0.0;
+  if (blockIdx.x == 0) {
+    if (k > 0) {
+      for (int r = wave * 8; r < pb; r += 128) {     // 16 waves x 8 rows a trip
+        double out[8];
+        rows(k + r, k + pb, out);
+        if (lane == 0)                               // (rows beyond pb: clamped repeats, never read)
+#pragma unroll
+          for (int u = 0; u < 8; ++u) sh.bl[r + u] = out[u];
+      }
+    } else {
+      for (int i = tid; i < pb; i += SWT) sh.bl[i] = b[i];
+    }
+    __syncthreads();
+    sweep_block_solve<0>(A + (size_t)k * ld + k, ld, pb, sh, tid);
+    for (int i = tid; i < pb; i += SWT) b[k + i] = sh.bl[i];
+  } else {
+    for (int r = k + PB + ((blockIdx.x - 1) * 16 + wave) * 4; r < n; r += (gridDim.x - 1) * 64) {
+      double out[4];
+      rows(r, n, out);
+      if (lane == 0)
+#pragma unroll
+        for (int u = 0; u < 4; ++u)
+          if (r + u < n) b[r + u] = out[u];
     }
   }
-  for (; r < nb; ++r) s0 += col[(size_t)r * ld] * xk[r];
-  if (c < k) b[c] -= s0 + s1;
+}
+
+// Backward, panel p at k = 256 p (pb entries); the panel after it (rows k + 256 .., pbn of them) is
+// solved.  Workgroup 0 solves panel p, workgroup j > 0 updates the columns 256 (j - 1) .. left of it.
+__global__ void __launch_bounds__(SWT)
+chol_bwd_step_kernel(const double* __restrict__ A, size_t ld, int n, int k, double* __restrict__ b) {
+  __shared__ SweepShared sh;
+  __shared__ double xn[PB];
+  const int tid = threadIdx.x;
+  const int pb = min(PB, n - k);
+  const int kn = k + PB, pbn = max(0, min(PB, n - kn));
+  for (int i = tid; i < pbn; i += SWT) xn[i] = b[kn + i];
+  if (tid == 0) sh.bl[PB] = 0.0;
+  __syncthreads();
+  // column c0 + (tid % 256) against x_next, the rows split in four quarters (tid / 256); the sum of
+  // the quarters lands in sh.red[0][.]
+  auto columns = [&](int c0, int ncols) -> double {
+    const int cl = tid & (PB - 1), q = tid >> 8;
+    const double* col = A + (size_t)kn * ld + c0 + min(cl, ncols - 1);
+    const int r_begin = q * 64, r_end = min(pbn, r_begin + 64);
+    double s0 = 0.0, s1 = 0.0;
+    for (int r = r_begin; r < r_end; r += 8) {
+      double v[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u) v[u] = col[(size_t)min(r + u, pbn - 1) * ld];
+#pragma unroll
+      for (int u = 0; u < 8; u += 2) {
+        s0 += (r + u < r_end) ? v[u] * xn[min(r + u, pbn - 1)] : 0.0;
+        s1 += (r + u + 1 < r_end) ? v[u + 1] * xn[min(r + u + 1, pbn - 1)] : 0.0;
+      }
+    }
+    sh.red[q][cl] = s0 + s1;
+    __syncthreads();
+    return (sh.red[0][cl] + sh.red[1][cl]) + (sh.red[2][cl] + sh.red[3][cl]);
+  };
+  if (blockIdx.x == 0) {
+    if (pbn > 0) {
+      const double t = columns(k, pb);
+      if (tid < pb) sh.bl[tid] = b[k + tid] - t;
+    } else {
+      if (tid < pb) sh.bl[tid] = b[k + tid];
+    }
+    __syncthreads();
+    sweep_block_solve<1>(A + (size_t)k * ld + k, ld, pb, sh, tid);
+    if (tid < pb) b[k + tid] = sh.bl[tid];
+  } else {
+    const int c0 = (blockIdx.x - 1) * PB;       // < k, a whole 256 columns (k is a multiple of 256)
+    const double t = columns(c0, PB);
+    if (tid < PB) b[c0 + tid] -= t;
+  }
 }
 
 // y[i] -= sum_j M[i][j] x[j] for an nrows x ncols piece of a row-major matrix (leading dimension
@@ -714,20 +914,20 @@ static int chol_factor_blocked(double* A, int n, int32_t* info_dev, hipStream_t 
 
 // sweeps: bit 0 = L y = b, bit 1 = L^T x = y; A is an n x n lower triangle with leading dimension ld
 static int chol_sweeps_blocked(const double* A, size_t ld, double* b, int n, int sweeps, hipStream_t s) {
-  const size_t lds = PB * sizeof(double);
+  const int np = (n + PB - 1) / PB;
   if (sweeps & 1)
-    for (int k = 0; k < n; k += PB) {
-      const int pb = std::min(PB, n - k);
-      trsv_fused_kernel<true><<<1, TRSV_T, lds, s>>>(A + (size_t)k * ld + k, (int)ld, pb, b + k, 0, 1);
-      const int rest = n - k - pb;
-      if (rest > 0)
-        chol_fwd_update_kernel<<<std::min((rest + 15) / 16, 4096), 256, 0, s>>>(A, ld, n, k, b);
+    for (int p = 0; p < np; ++p) {
+      const int k = p * PB;
+      // launch p: solve panel p (after taking panel p-1's solution out of it), and take panel p-1's
+      // solution out of the rows beyond panel p
+      const int rest = p > 0 ? std::max(0, n - k - PB) : 0;
+      chol_fwd_step_kernel<<<1 + std::min((rest + 63) / 64, 2048), SWT, 0, s>>>(A, ld, n, k, b);
     }
   if (sweeps & 2)
-    for (int k = (n - 1) / PB * PB; k >= 0; k -= PB) {
-      const int pb = std::min(PB, n - k);
-      trsv_fused_kernel<true><<<1, TRSV_T, lds, s>>>(A + (size_t)k * ld + k, (int)ld, pb, b + k, 1, 2);
-      if (k > 0) chol_bwd_update_kernel<<<(k + 255) / 256, 256, 0, s>>>(A, ld, k, pb, b);
+    for (int p = np - 1; p >= 0; --p) {
+      const int k = p * PB;
+      const int left = p < np - 1 ? k / PB : 0;      // 256-column groups left of panel p
+      chol_bwd_step_kernel<<<1 + left, SWT, 0, s>>>(A, ld, n, k, b);
     }
   HYDRA_CHECK_LAUNCH("hydra_chol_solve(blocked solve)");
   return HYDRA_OK;

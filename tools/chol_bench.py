@@ -28,3 +28,21 @@ for rep in range(2):
 res = float(torch.linalg.norm(A0 @ b - b0) / torch.linalg.norm(b0))
 fl = n ** 3 / 3.0
 print(f"{os.environ.get('HYDRA_HIP_LIBRARY', 'product')}: n={n}: {ms:.1f} ms = {fl / ms / 1e9:.2f} TFLOP/s = {fl / ms / 1e9 / 78.6:.3f} of peak; info {int(info.item())}, relative residual {res:.2e}")
+
+# the two triangular sweeps alone, from the kept factor (hydra_chol_apply: what a sample costs
+# when the operator has not changed)
+b = b0.clone()
+_dev.call("hydra_chol_apply", _dev.ptr(A), _dev.ptr(b), n, _dev.stream_ptr())
+torch.cuda.synchronize()
+reps = 5
+e0.record()
+for _ in range(reps):
+    _dev.call("hydra_chol_apply", _dev.ptr(A), _dev.ptr(b), n, _dev.stream_ptr())
+e1.record()
+torch.cuda.synchronize()
+ms = e0.elapsed_time(e1) / reps
+b = b0.clone()
+_dev.call("hydra_chol_apply", _dev.ptr(A), _dev.ptr(b), n, _dev.stream_ptr())
+res = float(torch.linalg.norm(A0 @ b - b0) / torch.linalg.norm(b0))
+print(f"  sweeps alone: {ms:.3f} ms = {8.0 * n * n / ms / 1e9:.2f} TB/s on the 2 x 4 n^2 bytes of L; "
+      f"relative residual {res:.2e}")
