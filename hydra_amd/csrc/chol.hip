@@ -198,6 +198,211 @@ syrk_update_kernel(double* __restrict__ A, size_t ld, int n, int k, int col_end,
   if (tid < 64) potrf_tile(sa, A, ld, base, min(NB, n - base), info, tid);
 }
 
+// ---- one launch per 32-column step ------------------------------------------------------------
+// The pair above is a chain of two dependent launches per block column (panel solve 9 us, update +
+// next diagonal block 14 us at n = 2000: 62 x 23 us = the 1.4 ms of config 2's factorisation).
+// chol_step_kernel does a whole step: the 64 x 64 tiles of the trailing update as before, and the
+// workgroups of the FIRST tile column go on to the next block column -- each forms the next
+// diagonal block D' = D - Pd Pd^T (32 x 32, from the panel rows it has staged anyway), factors it
+// (one wave, ~2 us, the same in every one of them) and solves its own 64 rows of the next panel
+// against it.  No workgroup waits for another.  What must not happen is a write to D while others
+// still read it, so the factored diagonal block is NOT stored by this launch: the next launch has
+// one extra workgroup (grid row nby) that forms and factors it again from the same inputs -- bit for
+// bit the same values -- and stores it, off the chain; chol_store_diag_kernel does that for the last
+// block of a panel.
+constexpr int STEP_T = 256;
+
+// sd <- D - Pd Pd^T for the nbd x nbd diagonal block at (kd, kd) (identity beyond nbd), Pd = rows
+// 0..31 of `pd` (the solved panel rows kd..kd+31 of the previous block column).  All STEP_T threads;
+// ends with a barrier.
+__device__ __forceinline__ void step_next_diag(const double* __restrict__ A, size_t ld, int n, int kd,
+                                               const double (*pd)[NB + 1], double (*sd)[NB + 1],
+                                               int tid) {
+  const int nbd = min(NB, n - kd);
+  double dv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + STEP_T * q, i = e / NB, j = e % NB;
+    dv[q] = A[(size_t)min(kd + i, n - 1) * ld + min(kd + j, n - 1)];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + STEP_T * q, i = e / NB, j = e % NB;
+    double acc = 0.0;
+#pragma unroll 8
+    for (int c = 0; c < NB; ++c) acc += pd[i][c] * pd[j][c];
+    sd[i][j] = (i < nbd && j < nbd) ? ((j <= i) ? dv[q] - acc : 0.0) : (i == j ? 1.0 : 0.0);
+  }
+  __syncthreads();
+}
+
+// factor sd in place (first wave); dinv <- reciprocals of the diagonal.  Returns "a pivot was bad"
+// in every lane of the first wave.
+__device__ __forceinline__ bool step_potrf(double (*sd)[NB + 1], double* dinv, int lane) {
+  const int i = lane & (NB - 1);
+  double v[NB];
+#pragma unroll
+  for (int j = 0; j < NB; ++j) v[j] = sd[i][j];
+  const bool bad = potrf_wave(v, i);
+  if (lane < NB) {
+#pragma unroll
+    for (int j = 0; j < NB; ++j) sd[lane][j] = (j <= lane) ? v[j] : 0.0;
+    dinv[lane] = 1.0 / sd[lane][lane];   // (read back: v[lane] would index the registers by lane)
+  }
+  return bad;
+}
+
+// panel rows kd..kd+31 of the block column at kprev (32 x 32) into pd; all STEP_T threads, no barrier
+__device__ __forceinline__ void step_load_pd(const double* __restrict__ A, size_t ld, int n, int kd,
+                                             int kprev, double (*pd)[NB + 1], int tid) {
+  double pv[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + STEP_T * q, i = e / NB, j = e % NB;
+    pv[q] = A[(size_t)min(kd + i, n - 1) * ld + kprev + j];
+  }
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + STEP_T * q, i = e / NB, j = e % NB;
+    pd[i][j] = (kd + i < n) ? pv[q] : 0.0;
+  }
+}
+
+// store the factored diagonal block at (kd, kd): formed from the panel columns kd-32..kd-1 as in
+// the step that used it
+__device__ __forceinline__ void step_store_diag(double* __restrict__ A, size_t ld, int n, int kd,
+                                                double (*pd)[NB + 1], double (*sd)[NB + 1],
+                                                double* dinv, int32_t* __restrict__ info, int tid) {
+  step_load_pd(A, ld, n, kd, kd - NB, pd, tid);
+  __syncthreads();
+  step_next_diag(A, ld, n, kd, pd, sd, tid);
+  if (tid < 64) {
+    const bool bad = step_potrf(sd, dinv, tid);
+    if (bad && tid == 0) atomicOr(info, 1);
+  }
+  __syncthreads();
+  const int nbd = min(NB, n - kd);
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int e = tid + STEP_T * q, i = e / NB, j = e % NB;
+    if (i < nbd && j <= i) A[(size_t)(kd + i) * ld + kd + j] = sd[i][j];
+  }
+}
+
+__global__ void __launch_bounds__(STEP_T)
+chol_store_diag_kernel(double* __restrict__ A, size_t ld, int n, int kd, int32_t* __restrict__ info) {
+  __shared__ double pd[NB][NB + 1], sd[NB][NB + 1];
+  __shared__ double dinv[NB];
+  step_store_diag(A, ld, n, kd, pd, sd, dinv, info, threadIdx.x);
+}
+
+// Step at block column k (full, with rows below): trailing update of the columns [k+32, col_end),
+// next diagonal block and next panel.  Grid (column tiles, row tiles + 1); store_prev: the diagonal
+// block at k is still to be stored (it was formed by the previous step, not by potrf_diag_kernel).
+__global__ void __launch_bounds__(STEP_T)
+chol_step_kernel(double* __restrict__ A, size_t ld, int n, int k, int col_end, int store_prev,
+                 int32_t* __restrict__ info) {
+  __shared__ double sa[SY_T][NB + 1], sb[SY_T][NB + 1];
+  __shared__ double sd[NB][NB + 1];
+  __shared__ double dinv[NB];
+  const int base = k + NB;
+  const int bi = blockIdx.y, bj = blockIdx.x, nby = gridDim.y - 1;
+  const int tid = threadIdx.x, ty = tid / 16, tx = tid % 16;
+  if (bi == nby) {                 // the extra row: its first workgroup stores the diagonal block at k
+    if (bj == 0 && store_prev) step_store_diag(A, ld, n, k, sa, sd, dinv, info, tid);
+    return;
+  }
+  if (bj > bi) return;
+  const int i0 = base + bi * SY_T, j0 = base + bj * SY_T;
+  {
+    const int c = tid % NB, r = tid / NB;   // 8 panel rows per trip, loads along the rows
+    double pa[SY_T / 8], pb[SY_T / 8];
+#pragma unroll
+    for (int q = 0; q < SY_T / 8; ++q) {
+      pa[q] = A[(size_t)min(i0 + r + 8 * q, n - 1) * ld + k + c];
+      pb[q] = A[(size_t)min(j0 + r + 8 * q, n - 1) * ld + k + c];
+    }
+#pragma unroll
+    for (int q = 0; q < SY_T / 8; ++q) {
+      sa[r + 8 * q][c] = (i0 + r + 8 * q < n) ? pa[q] : 0.0;
+      sb[r + 8 * q][c] = (j0 + r + 8 * q < n) ? pb[q] : 0.0;
+    }
+  }
+  double old[4][4];
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      int gi = i0 + ty + 16 * a, gj = j0 + tx + 16 * b;
+      old[a][b] = (gi < n && gj <= gi && gj < col_end) ? A[(size_t)gi * ld + gj] : 0.0;
+    }
+  __syncthreads();
+  double acc[4][4] = {};
+#pragma unroll 8
+  for (int c = 0; c < NB; ++c) {
+    double ra[4], rb[4];
+#pragma unroll
+    for (int a = 0; a < 4; ++a) ra[a] = sa[ty + 16 * a][c];
+#pragma unroll
+    for (int b = 0; b < 4; ++b) rb[b] = sb[tx + 16 * b][c];
+#pragma unroll
+    for (int a = 0; a < 4; ++a)
+#pragma unroll
+      for (int b = 0; b < 4; ++b) acc[a][b] += ra[a] * rb[b];
+  }
+  const bool first = bj == 0;      // this tile's first 32 columns are the next panel
+  const bool solve = first && n - base > NB;   // ... and there are rows below the next diagonal block
+  if (first) {
+    // the next diagonal block, from the panel rows base..base+31 = the first 32 rows of sb
+    step_next_diag(A, ld, n, base, sb, sd, tid);     // (ends with a barrier: sa is free after it)
+  }
+#pragma unroll
+  for (int a = 0; a < 4; ++a)
+#pragma unroll
+    for (int b = 0; b < 4; ++b) {
+      const int li = ty + 16 * a, lj = tx + 16 * b;
+      const int gi = i0 + li, gj = j0 + lj;
+      const double val = old[a][b] - acc[a][b];
+      if (first && lj < NB) {
+        // next panel: rows of the diagonal block are left alone (stored by the next launch),
+        // rows below it go through the solve
+        if (solve) sa[li][lj] = val;
+      } else if (gi < n && gj <= gi && gj < col_end) {
+        A[(size_t)gi * ld + gj] = val;
+      }
+    }
+  if (!first) return;
+  if (tid < 64) step_potrf(sd, dinv, tid);           // (a bad pivot is reported by the storing workgroup)
+  __syncthreads();
+  if (!solve) return;
+  if (tid < SY_T) {                // thread <-> row: v <- v L11^-T
+    double v[NB];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) v[j] = sa[tid][j];
+#pragma unroll
+    for (int j = 0; j < NB; ++j) {
+      double t0 = v[j], t1 = 0.0;
+#pragma unroll
+      for (int c = 0; c < NB; ++c) {
+        if (c < j) {               // (j and c are constants once unrolled)
+          if (c & 1) t1 -= v[c] * sd[j][c];
+          else       t0 -= v[c] * sd[j][c];
+        }
+      }
+      v[j] = (t0 + t1) * dinv[j];
+    }
+#pragma unroll
+    for (int j = 0; j < NB; ++j) sa[tid][j] = v[j];
+  }
+  __syncthreads();
+#pragma unroll
+  for (int q = 0; q < SY_T / 8; ++q) {
+    const int li = tid / NB + 8 * q, j = tid % NB;
+    const int gi = i0 + li;
+    if (gi >= base + NB && gi < n) A[(size_t)gi * ld + base + j] = sa[li][j];
+  }
+}
+
 // Both triangular solves of the Cholesky fallback in ONE launch by one workgroup of NB*NB threads
 // (a kernel pair per block column needs 4 n / NB launches of 5-18 us each, most of the solve time
 // at n ~ 2000).  Left-looking: block k of the solution needs sum_j L[k, j] y_j over the blocks
@@ -831,16 +1036,41 @@ static int chol_solve_any(const double* A, double* b, int n, hipStream_t s) {
   return chol_small_solve(A, b, n, s);
 }
 
-static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_t s) {
+// the 32-wide steps of the columns [k, col_end) of an n-row array: one launch per step
+// (chol_step_kernel) after the first block column's own two
+#ifndef HYDRA_CHOL_FUSED_STEP
+#define HYDRA_CHOL_FUSED_STEP 1
+#endif
+static void steps_fused(double* A, size_t ld, int n, int k, int col_end, int32_t* info_dev,
+                        hipStream_t s) {
   dim3 tb(NB, NB);
-  potrf_diag_kernel<<<1, tb, 0, s>>>(A, (size_t)n, n, 0, info_dev);
-  for (int k = 0; k < n; k += NB) {
-    int nb = std::min(NB, n - k);
-    int rest = n - k - nb;
-    if (rest > 0) {   // then the block is full (nb == NB)
-      trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, (size_t)n, n, k);
-      int nblk = (rest + SY_T - 1) / SY_T;
-      syrk_update_kernel<<<dim3(nblk, nblk), 256, 0, s>>>(A, (size_t)n, n, k, n, info_dev);  // + potrf of block k+NB
+  potrf_diag_kernel<<<1, tb, 0, s>>>(A, ld, n, k, info_dev);
+  if (n - k - NB <= 0) return;                     // nothing below the first block
+  trsm_panel_kernel<<<(n - k - NB + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, ld, n, k);
+  int last = -1;
+  for (int kk = k; col_end - (kk + NB) > 0 && n - kk - NB > 0; kk += NB) {
+    const int base = kk + NB;
+    const int nct = (col_end - base + SY_T - 1) / SY_T, nrt = (n - base + SY_T - 1) / SY_T;
+    chol_step_kernel<<<dim3(nct, nrt + 1), STEP_T, 0, s>>>(A, ld, n, kk, col_end, kk > k, info_dev);
+    last = base;
+  }
+  if (last >= 0) chol_store_diag_kernel<<<1, STEP_T, 0, s>>>(A, ld, n, last, info_dev);
+}
+
+static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_t s) {
+  if (HYDRA_CHOL_FUSED_STEP) {
+    steps_fused(A, (size_t)n, n, 0, n, info_dev, s);
+  } else {
+    dim3 tb(NB, NB);
+    potrf_diag_kernel<<<1, tb, 0, s>>>(A, (size_t)n, n, 0, info_dev);
+    for (int k = 0; k < n; k += NB) {
+      int nb = std::min(NB, n - k);
+      int rest = n - k - nb;
+      if (rest > 0) {   // then the block is full (nb == NB)
+        trsm_panel_kernel<<<(rest + TRSM_T - 1) / TRSM_T, TRSM_T, 0, s>>>(A, (size_t)n, n, k);
+        int nblk = (rest + SY_T - 1) / SY_T;
+        syrk_update_kernel<<<dim3(nblk, nblk), 256, 0, s>>>(A, (size_t)n, n, k, n, info_dev);  // + potrf of block k+NB
+      }
     }
   }
   HYDRA_CHECK_LAUNCH("hydra_chol_solve(factor)");
@@ -866,6 +1096,7 @@ static_assert(SPW % PB == 0, "super-panel = whole 256-wide panels");
 // [k, col_end) updated after every step (the update that completes a 32-block factors it).
 static void factor_panel(double* A, size_t ld, int n, int k, int col_end, int32_t* info_dev,
                          hipStream_t s) {
+  if (HYDRA_CHOL_FUSED_STEP) return steps_fused(A, ld, n, k, col_end, info_dev, s);
   dim3 tb(NB, NB);
   potrf_diag_kernel<<<1, tb, 0, s>>>(A, ld, n, k, info_dev);
   for (int kk = k; kk < col_end; kk += NB) {

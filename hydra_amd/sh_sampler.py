@@ -263,6 +263,38 @@ class LhsOperator:
         return _dev.like(a_cr, tot + self.ip * a)
 
 
+#: form Y^T G Y with torch's GEMM (a library call) instead of this package's matrix-core kernel
+PROJECT_WITH_LIBRARY_GEMM = False
+
+
+def _project_sym(G, ymap):
+    """Lower triangle of Y^T G Y for a symmetric G (Nv, Nv) and the mode maps Y (Nv, Nm): the two
+    products of the closed-form left-hand side.  Both run on the FP64 matrix cores through
+    ``hydra_chol_update_rect`` (C[i][j] -= sum_k PA[i][k] PB[j][k], the update kernel of the dense
+    solve: row-major operands with k along the rows, which is how Y^T and the symmetric G lie):
+    C1 = -(Y^T G), then A = -(C1 Y) on and below the diagonal.  k is padded to the kernel's 16."""
+    if PROJECT_WITH_LIBRARY_GEMM:
+        return ymap.T @ (G @ ymap)
+    nv, nm = ymap.shape
+    nvp = -(-nv // 16) * 16
+    dev = G.device
+    yt = torch.zeros((nm, nvp), dtype=torch.float64, device=dev)
+    yt[:, :nv] = ymap.T
+    if nvp != nv or not G.is_contiguous():
+        gp = torch.zeros((nv, nvp), dtype=torch.float64, device=dev)
+        gp[:, :nv] = G
+    else:
+        gp = G
+    st = _dev.stream_ptr()
+    c1 = torch.zeros((nm, nvp), dtype=torch.float64, device=dev)
+    _dev.call("hydra_chol_update_rect", _dev.ptr(c1), nvp, _dev.ptr(yt), nvp, _dev.ptr(gp), nvp,
+              nm, nv, nv, nvp, st)
+    A = torch.zeros((nm, nm), dtype=torch.float64, device=dev)
+    _dev.call("hydra_chol_update_rect", _dev.ptr(A), nm, _dev.ptr(c1), nvp, _dev.ptr(yt), nvp,
+              nm, nm, 0, nvp, st)
+    return A
+
+
 class StreamedSHOperator:
     """The SH response operator of ``vis_proj_operator_no_rot`` WITHOUT its (Nvis, Nm) matrix in
     memory -- for time axes whose operator does not fit HBM (HERA-127, lmax 40, 128 channels:
@@ -361,8 +393,8 @@ class StreamedSHOperator:
             Gp = G if Gp is None else Gp.add_(G)
             del sub
         self.fac.last_gram_kernel = "gram_uniform_kernel"
-        A = ymap.T @ (Gp @ ymap)
-        # the product is symmetric up to rounding; the solvers read half of a matrix marked symmetric
+        A = _project_sym(Gp, ymap)
+        # only the lower triangle is formed; the solvers read half of a matrix marked symmetric
         return torch.tril(A) + torch.tril(A, -1).T
 
     def lhs_matrix(self, inv_noise_var, inv_prior_var, comm=None, closed_form=True):
