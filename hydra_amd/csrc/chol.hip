@@ -4,6 +4,7 @@
 //   * larger n: 256-wide panels with the trailing update on the FP64 matrix cores and
 //     multi-workgroup triangular solves (config 5: 100 000 unknowns).
 #include <algorithm>
+#include <cstdlib>
 
 #include "common.h"
 
@@ -1038,9 +1039,17 @@ static int chol_solve_any(const double* A, double* b, int n, hipStream_t s) {
 
 // the 32-wide steps of the columns [k, col_end) of an n-row array: one launch per step
 // (chol_step_kernel) after the first block column's own two
-#ifndef HYDRA_CHOL_FUSED_STEP
-#define HYDRA_CHOL_FUSED_STEP 1
+// (off until it has passed the GPU suite: HYDRA_CHOL_FUSED_STEP=1 in the environment turns it on)
+#ifndef HYDRA_CHOL_FUSED_STEP_DEFAULT
+#define HYDRA_CHOL_FUSED_STEP_DEFAULT 0
 #endif
+static bool chol_fused_step() {
+  static const bool on = [] {
+    const char* e = getenv("HYDRA_CHOL_FUSED_STEP");
+    return e ? atoi(e) != 0 : HYDRA_CHOL_FUSED_STEP_DEFAULT != 0;
+  }();
+  return on;
+}
 static void steps_fused(double* A, size_t ld, int n, int k, int col_end, int32_t* info_dev,
                         hipStream_t s) {
   dim3 tb(NB, NB);
@@ -1058,7 +1067,7 @@ static void steps_fused(double* A, size_t ld, int n, int k, int col_end, int32_t
 }
 
 static int chol_small(double* A, double* b, int n, int32_t* info_dev, hipStream_t s) {
-  if (HYDRA_CHOL_FUSED_STEP) {
+  if (chol_fused_step()) {
     steps_fused(A, (size_t)n, n, 0, n, info_dev, s);
   } else {
     dim3 tb(NB, NB);
@@ -1096,7 +1105,7 @@ static_assert(SPW % PB == 0, "super-panel = whole 256-wide panels");
 // [k, col_end) updated after every step (the update that completes a 32-block factors it).
 static void factor_panel(double* A, size_t ld, int n, int k, int col_end, int32_t* info_dev,
                          hipStream_t s) {
-  if (HYDRA_CHOL_FUSED_STEP) return steps_fused(A, ld, n, k, col_end, info_dev, s);
+  if (chol_fused_step()) return steps_fused(A, ld, n, k, col_end, info_dev, s);
   dim3 tb(NB, NB);
   potrf_diag_kernel<<<1, tb, 0, s>>>(A, ld, n, k, info_dev);
   for (int kk = k; kk < col_end; kk += NB) {

@@ -14,6 +14,8 @@ Spherical-harmonic diffuse head on MI355X -- drop-in for the GCR functions of
 cores for callers that iterate many times.  The GSM helpers of the reference module need pygdsm
 data files and are not provided; ``sample_cl`` is a stub there.
 """
+import os
+
 import numpy as np
 import torch
 
@@ -264,7 +266,8 @@ class LhsOperator:
 
 
 #: form Y^T G Y with torch's GEMM (a library call) instead of this package's matrix-core kernel
-PROJECT_WITH_LIBRARY_GEMM = False
+#: (the default until the kernel route has passed the GPU suite: HYDRA_SH_OWN_GEMM=1 selects it)
+PROJECT_WITH_LIBRARY_GEMM = os.environ.get("HYDRA_SH_OWN_GEMM", "0") == "0"
 
 
 def _project_sym(G, ymap):
