@@ -335,7 +335,8 @@ def main_sh_streamed(args, comm, rank, world, dev):
         "sample_rel_residual": resid,
         "roofline": ({
             "bound": "mfma", "achieved": flops / (adj_ms * 1e-3) / 1e12, "peak": 78.6,
-            "unit": "TFLOP/s", "frac": flops / (adj_ms * 1e-3) / 1e12 / 78.6, "traffic": None,
+            "unit": "TFLOP/s", "frac": flops / (adj_ms * 1e-3) / 1e12 / 78.6,
+            "traffic": pmc_traffic(args.config, "adjoint_V_big_kernel") if world == 1 else None,
             "kernel": "adjoint_V_big_kernel (R^H z in antenna space, W = Zc V on FP64 MFMA) + Y^T GEMV",
             "ms_per_launch": adj_ms, "flops_per_launch": flops,
             "hbm_GBps": vbytes / (adj_ms * 1e-3) / 1e9,
