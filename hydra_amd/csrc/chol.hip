@@ -1039,9 +1039,9 @@ static int chol_solve_any(const double* A, double* b, int n, hipStream_t s) {
 
 // the 32-wide steps of the columns [k, col_end) of an n-row array: one launch per step
 // (chol_step_kernel) after the first block column's own two
-// (off until it has passed the GPU suite: HYDRA_CHOL_FUSED_STEP=1 in the environment turns it on)
+// (HYDRA_CHOL_FUSED_STEP=0 in the environment selects the two-launch form, for comparison)
 #ifndef HYDRA_CHOL_FUSED_STEP_DEFAULT
-#define HYDRA_CHOL_FUSED_STEP_DEFAULT 0
+#define HYDRA_CHOL_FUSED_STEP_DEFAULT 1
 #endif
 static bool chol_fused_step() {
   static const bool on = [] {

@@ -266,8 +266,8 @@ class LhsOperator:
 
 
 #: form Y^T G Y with torch's GEMM (a library call) instead of this package's matrix-core kernel
-#: (the default until the kernel route has passed the GPU suite: HYDRA_SH_OWN_GEMM=1 selects it)
-PROJECT_WITH_LIBRARY_GEMM = os.environ.get("HYDRA_SH_OWN_GEMM", "0") == "0"
+#: (HYDRA_SH_OWN_GEMM=0 selects the library call, for comparison)
+PROJECT_WITH_LIBRARY_GEMM = os.environ.get("HYDRA_SH_OWN_GEMM", "1") == "0"
 
 
 def _project_sym(G, ymap):
