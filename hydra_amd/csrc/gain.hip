@@ -855,15 +855,25 @@ __host__ __device__ inline int gm_elem(int a, int b) {
   return ((((a >> 2) << 2) + (b >> 2)) << 4) + ((a & 3) << 2) + (b & 3);
 }
 
-// One workgroup per (block, 4 consecutive chunks = 8 samples): thread (a, b) reads its pair's model
-// and noise weight for 8 consecutive samples (one 128-byte / 64-byte run each) and writes the
-// entry of the 4 chunks.  gains == NULL: model_vis already carries them.
-constexpr int GM_WB_GROUPS = 16;
+// One workgroup per (block, GM_WB_GROUPS groups of 16 consecutive samples).  The inputs are
+// pair-major ((Nbl, Nft): a pair's samples are contiguous), the block layout is sample-major (a
+// sample's 256 entries are contiguous), so a group goes through LDS: thread (p, s) = (tid / 16,
+// tid % 16) reads sample s of pair slots p, p + 16, ... (256-byte runs of the model, 128-byte runs of
+// the noise weights, every line used whole) into tile[s][entry]; then the 16 samples leave as
+// 2 KiB rows, 16 bytes per thread.  (The first form had thread <-> pair with 8 samples in a loop:
+// 8.4 ms and 56 GB fetched for 5.4 GB of inputs at config 4 -- every 16-byte piece pulled its line
+// again.)  gains == NULL: model_vis already carries them.
+constexpr int GM_WB_GROUPS = 4;
+constexpr int GM_WB_S = 16;                   // samples per group
+constexpr int GM_WB_ROW = 256 + 2;            // tile row (doubles): +2 keeps the 16 samples on 16 bank pairs
+static_assert(GM_WB_S % GM_FT == 0, "a group holds whole chunks");
 __global__ void __launch_bounds__(256)
 gain_weights_blocks_kernel(const f64x2* __restrict__ mv, const f64x2* __restrict__ gains,
                            const double* __restrict__ w, const int32_t* __restrict__ pairb, int nant,
                            int nft, int nb, double* __restrict__ Wb) {
-  const int a = threadIdx.x >> 4, b = threadIdx.x & 15;
+  __shared__ __align__(16) double tile[GM_WB_S * GM_WB_ROW];
+  __shared__ int s_pair[256];
+  const int tid = threadIdx.x;
   int A = 0, B;
   {
     int base = 0;
@@ -872,35 +882,47 @@ gain_weights_blocks_kernel(const f64x2* __restrict__ mv, const f64x2* __restrict
     B = A + (blk - base);
   }
   const long long nblk = (long long)nb * (nb + 1) / 2;
-  const int ag = 16 * A + a, bg = 16 * B + b;
-  int pair = -1;
-  if (ag < nant && bg < nant && ag != bg) pair = pairb[(size_t)ag * nant + bg];
-  // several groups of 8 samples per workgroup (one group each made 118 000 workgroups of a few
-  // hundred cycles at config 4: 8.3 ms, bound by their dispatch)
-  for (int grp = blockIdx.y * GM_WB_GROUPS; grp < min((blockIdx.y + 1) * GM_WB_GROUPS, (nft + 7) / 8); ++grp) {
-    const int ft0 = grp * 8;
-    double val[8];
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const int ft = min(ft0 + u, nft - 1);
+  {
+    const int a = tid >> 4, b = tid & 15;
+    const int ag = 16 * A + a, bg = 16 * B + b;
+    s_pair[tid] = (ag < nant && bg < nant && ag != bg) ? pairb[(size_t)ag * nant + bg] : -1;
+  }
+  __syncthreads();
+  const int p = tid >> 4, sl = tid & 15;
+  const int ngroups = (nft + GM_WB_S - 1) / GM_WB_S;
+  for (int grp = blockIdx.y * GM_WB_GROUPS; grp < min((blockIdx.y + 1) * GM_WB_GROUPS, ngroups); ++grp) {
+    const int ft0 = grp * GM_WB_S;
+    const int ft = min(ft0 + sl, nft - 1);
+#pragma unroll 4
+    for (int it = 0; it < 16; ++it) {
+      const int slot = it * 16 + p;            // (a, b) = (slot / 16, slot % 16)
+      const int pair = s_pair[slot];
       double v = 0.0;
       if (pair >= 0) {
         const f64x2 m = mv[(size_t)pair * nft + ft];
         v = (m.x * m.x + m.y * m.y) * (w ? w[(size_t)pair * nft + ft] : 1.0);
         if (gains) {
+          const int ag = 16 * A + (slot >> 4), bg = 16 * B + (slot & 15);
           const f64x2 ga = gains[(size_t)ag * nft + ft], gb = gains[(size_t)bg * nft + ft];
           v *= (ga.x * ga.x + ga.y * ga.y) * (gb.x * gb.x + gb.y * gb.y);
         }
       }
-      val[u] = (ft0 + u < nft) ? v : 0.0;
+      tile[sl * GM_WB_ROW + gm_elem(slot >> 4, slot & 15)] = (ft0 + sl < nft) ? v : 0.0;
     }
+    __syncthreads();
+    // out: sample s of the group is entry f = s % GM_FT of chunk (ft0 + s) / GM_FT, 256 doubles
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      const long long chunk = (ft0 + u) / GM_FT;
-      const int f = (ft0 + u) % GM_FT;
-      if ((long long)chunk * GM_FT >= nft) break;
-      Wb[((chunk * nblk + blockIdx.x) * GM_FT + f) * 256 + gm_elem(a, b)] = val[u];
+    for (int q = 0; q < GM_WB_S * 128 / 256; ++q) {
+      const int e = q * 256 + tid;             // 16-byte piece e of the group: sample e / 128, piece e % 128
+      const int so = e >> 7, pc = e & 127;
+      const long long chunk = (ft0 + so) / GM_FT;
+      const int f = (ft0 + so) % GM_FT;
+      if (chunk * GM_FT < nft) {               // (the chunk exists; samples beyond nft in it are zeros)
+        const f64x2 val = *reinterpret_cast<const f64x2*>(&tile[so * GM_WB_ROW + 2 * pc]);
+        *reinterpret_cast<f64x2*>(&Wb[((chunk * nblk + blockIdx.x) * GM_FT + f) * 256 + 2 * pc]) = val;
+      }
     }
+    __syncthreads();
   }
 }
 
@@ -1569,7 +1591,7 @@ int hydra_gain_weights_blocks(const double* model_vis, const double* gains, cons
   HYDRA_CHECK_ARG(hydra_gain_blocks_weight_count(nant, nft) != 0,
                   "hydra_gain_weights_blocks: %d antennas do not fit the block layout", nant);
   const int nb = (nant + 15) / 16;
-  const int ngroups = ((nft + 7) / 8 + GM_WB_GROUPS - 1) / GM_WB_GROUPS;
+  const int ngroups = ((nft + GM_WB_S - 1) / GM_WB_S + GM_WB_GROUPS - 1) / GM_WB_GROUPS;
   HYDRA_CHECK_ARG(ngroups <= 65535, "hydra_gain_weights_blocks: nft too large");
   dim3 grid(nb * (nb + 1) / 2, ngroups);
   gain_weights_blocks_kernel<<<grid, 256, 0, as_stream(stream)>>>(
