@@ -1190,6 +1190,57 @@ gain_basis_fwd_blocks_kernel(const double* __restrict__ x, const f64x2* __restri
   }
 }
 
+// The same for up to NM modes with the roles turned round: a thread owns (antenna, vector) and keeps
+// its NM scaled amplitudes in registers, the basis values of 64 samples sit in LDS (every lane reads
+// the same one: broadcasts), and per sample the 32 antennas x 8 vectors of a workgroup store 4 KiB in
+// one piece -- in the kernel above a lane owns a sample, and its eight 16-byte stores of a row of Gc
+// land 43 KB from the next lane's (0.10 ms for 176 MB at config 4, most of it the stores).
+constexpr int GFB_ANT = 32, GFB_FT = 64;
+template <int NM>
+__global__ void __launch_bounds__(256)
+gain_basis_fwd_rows_kernel(const double* __restrict__ x, const f64x2* __restrict__ F,
+                           const double* __restrict__ s, int nant, int nmodes, int nft, int nap,
+                           int nftp, int v0, int nvec, f64x2* __restrict__ Gc) {
+  __shared__ f64x2 s_f[GFB_FT][NM];
+  const int tid = threadIdx.x;
+  const int v = tid & 7, a = blockIdx.y * GFB_ANT + (tid >> 3);
+  const int ft0 = blockIdx.x * GFB_FT;
+  for (int e = tid; e < GFB_FT * NM; e += 256) {
+    const int m = e / GFB_FT, fl = e % GFB_FT;
+    const f64x2 f = F[(size_t)min(m, nmodes - 1) * nft + min(ft0 + fl, nft - 1)];
+    s_f[fl][m] = (m < nmodes) ? f : f64x2{0.0, 0.0};
+  }
+  f64x2 z[NM];
+  {
+    const bool live = a < nant && v0 + v < nvec;
+    const double* xre = x + (size_t)min(v0 + v, nvec - 1) * 2 * nant * nmodes +
+                        (size_t)min(a, nant - 1) * nmodes;
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const int mc = min(m, nmodes - 1);
+      const double sm = s ? s[mc] : 1.0;
+      const f64x2 t = f64x2{sm * xre[mc], sm * xre[mc + (size_t)nant * nmodes]};
+      z[m] = (live && m < nmodes) ? t : f64x2{0.0, 0.0};
+    }
+  }
+  __syncthreads();
+  if (a >= nap) return;
+  for (int fl = 0; fl < GFB_FT; ++fl) {
+    const int ft = ft0 + fl;
+    if (ft >= nftp) break;
+    f64x2 acc = {0.0, 0.0};
+#pragma unroll
+    for (int m = 0; m < NM; ++m) {
+      const f64x2 f = s_f[fl][m];
+      acc.x = __builtin_fma(f.x, z[m].x, acc.x);
+      acc.x = __builtin_fma(-f.y, z[m].y, acc.x);
+      acc.y = __builtin_fma(f.x, z[m].y, acc.y);
+      acc.y = __builtin_fma(f.y, z[m].x, acc.y);
+    }
+    Gc[((size_t)ft * nap + a) * 8 + v] = (ft < nft) ? f64x2{acc.x, -acc.y} : f64x2{0.0, 0.0};
+  }
+}
+
 // out[v0+v, a*nmodes+m] = Re, out[v0+v, nant*nmodes + a*nmodes+m] = Im of
 //   s_m sum_ft conj(F[m,ft]) y[v,a,ft]  (+ add) with y in the sample-major layout Yc[ft][a][16].
 // One workgroup of 16 waves per antenna: wave (half q, mode group mg) sums the samples
@@ -1644,8 +1695,16 @@ int hydra_gain_operator_blocks(const double* x, int nvec, int nant, int nmodes, 
     HYDRA_CHECK_LAUNCH("hydra_gain_operator_blocks(basis table)");
   }
   for (int v0 = 0; v0 < nvec; v0 += GM_NV) {
-    gain_basis_fwd_blocks_kernel<<<dim3((nftp + 63) / 64, nap / 4), 256, 0, st>>>(
-        x, Fp, pspec_sqrt, nant, nmodes, nft, nap, nftp, v0, nvec, reinterpret_cast<f64x2*>(Gc));
+    const dim3 grows((nftp + GFB_FT - 1) / GFB_FT, (nap + GFB_ANT - 1) / GFB_ANT);
+    if (nmodes <= 16)
+      gain_basis_fwd_rows_kernel<16><<<grows, 256, 0, st>>>(
+          x, Fp, pspec_sqrt, nant, nmodes, nft, nap, nftp, v0, nvec, reinterpret_cast<f64x2*>(Gc));
+    else if (nmodes <= 32)
+      gain_basis_fwd_rows_kernel<32><<<grows, 256, 0, st>>>(
+          x, Fp, pspec_sqrt, nant, nmodes, nft, nap, nftp, v0, nvec, reinterpret_cast<f64x2*>(Gc));
+    else
+      gain_basis_fwd_blocks_kernel<<<dim3((nftp + 63) / 64, nap / 4), 256, 0, st>>>(
+          x, Fp, pspec_sqrt, nant, nmodes, nft, nap, nftp, v0, nvec, reinterpret_cast<f64x2*>(Gc));
     HYDRA_CHECK_LAUNCH("hydra_gain_operator_blocks(basis)");
     if (int rc = launch_pairs_mfma<true>(Gc, nvec, nant, nft, Wb, sw, Yc, v0, st)) return rc;
     if (nmodes <= 8)
