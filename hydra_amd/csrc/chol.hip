@@ -1043,6 +1043,7 @@ static int chol_solve_any(const double* A, double* b, int n, hipStream_t s) {
 #ifndef HYDRA_CHOL_FUSED_STEP_DEFAULT
 #define HYDRA_CHOL_FUSED_STEP_DEFAULT 1
 #endif
+static constexpr int CHOL_FUSED_STEP_MAX_ROWS = 8192;
 static bool chol_fused_step() {
   static const bool on = [] {
     const char* e = getenv("HYDRA_CHOL_FUSED_STEP");
@@ -1104,8 +1105,12 @@ static_assert(SPW % PB == 0, "super-panel = whole 256-wide panels");
 // block at (k,k) is factored, the rows below it solved against it, and the columns still inside
 // [k, col_end) updated after every step (the update that completes a 32-block factors it).
 static void factor_panel(double* A, size_t ld, int n, int k, int col_end, int32_t* info_dev,
-                         hipStream_t s) {
-  if (chol_fused_step()) return steps_fused(A, ld, n, k, col_end, info_dev, s);
+                         hipStream_t s, bool allow_fused = true) {
+  // (every workgroup of the first tile column factors the next diagonal block for itself: with many
+  // rows below that redundant single-wave work outweighs the launch it saves -- n = 100 000: 61 us
+  // per step against 28 + 13 -- so tall panels keep the two-launch form)
+  if (allow_fused && chol_fused_step() && n - k <= CHOL_FUSED_STEP_MAX_ROWS)
+    return steps_fused(A, ld, n, k, col_end, info_dev, s);
   dim3 tb(NB, NB);
   potrf_diag_kernel<<<1, tb, 0, s>>>(A, ld, n, k, info_dev);
   for (int kk = k; kk < col_end; kk += NB) {
@@ -1220,7 +1225,10 @@ int hydra_chol_panel(double* P, long long ld, int nrows, int ncols, int32_t* inf
                   "hydra_chol_panel: bad arguments (nrows=%d ncols=%d ld=%lld)", nrows, ncols, ld);
   HYDRA_CHECK_ARG(nrows == ncols || ncols % NB == 0,
                   "hydra_chol_panel: a panel with rows below it must be whole 32-column steps");
-  factor_panel(P, (size_t)ld, nrows, 0, ncols, info_dev, as_stream(stream));
+  // (always the two-launch steps: the ranks of a row-sharded factorisation factor the diagonal block
+  // redundantly on panels of different heights, and a choice by height would give them factors that
+  // differ in the last bit)
+  factor_panel(P, (size_t)ld, nrows, 0, ncols, info_dev, as_stream(stream), false);
   HYDRA_CHECK_LAUNCH("hydra_chol_panel");
   return HYDRA_OK;
 }
