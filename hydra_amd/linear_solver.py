@@ -328,9 +328,9 @@ def cho_factor(Amat, overwrite_a=False, inverse_factor=None):
         inverse_factor = n <= INVERSE_FACTOR_MAX_N
     if not inverse_factor:
         return CholeskyFactor(A, n)
-    # L X = I by the BLAS triangular solve (set-up, once per matrix)
-    eye = torch.eye(n, dtype=torch.float64, device=A.device)
-    linv = torch.linalg.solve_triangular(torch.tril(A[:n, :n]), eye, upper=False).contiguous()
+    # X = L^-1 (set-up, once per matrix), column block by column block (csrc/chol.hip)
+    linv = torch.empty((n, n), dtype=torch.float64, device=A.device)
+    _dev.call("hydra_tri_inverse", _dev.ptr(A), A.shape[1], n, _dev.ptr(linv), n, _dev.stream_ptr())
     return CholeskyFactor(A, n, linv, linv.T.contiguous())
 
 

@@ -374,6 +374,14 @@ int hydra_chol_solve(double* A, double* b, int n, int32_t* info_dev, void* strea
  * (example.py:1014-1052).  Same alignment rules as hydra_chol_solve.                        */
 int hydra_chol_apply(const double* L, double* b, int n, void* stream);
 
+/* X <- L^-1 for the lower-triangular factor hydra_chol_solve left in A (row stride ld; what lies
+ * above the diagonal of L is not read), X (n, n) with row stride ldx, zero above the diagonal.
+ * For the same constant systems (sh_sampler.py:389-402, example.py:1014-1052) at small n, where
+ * two matrix-vector products with L^-1 and L^-T beat the two substitution chains of
+ * hydra_chol_apply (hydra_amd.linear_solver.cho_factor(inverse_factor=True)): done once per
+ * matrix, column block by column block, one workgroup per 32 columns.                      */
+int hydra_tri_inverse(const double* L, long long ld, int n, double* X, long long ldx, void* stream);
+
 /* The large-matrix algorithm behind hydra_chol_solve (taken automatically for even n >= 6144):
  * 256-wide panels factored by 32-wide steps, then ONE rank-256 update of the rest of the lower
  * triangle per panel on the FP64 matrix cores (C -= P P^T, P = the finished panel read in place),

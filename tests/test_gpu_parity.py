@@ -518,6 +518,28 @@ def test_cho_factor_then_solves_match_scipy(hy, n):
         hy.linear_solver.cho_factor(A - 2 * np.diag(np.diag(A)))
 
 
+@pytest.mark.parametrize("n", [1, 5, 32, 33, 100, 1000, 1681, 4096])
+def test_triangular_inverse_kernel(hy, n):
+    """hydra_tri_inverse (the inverse of the Cholesky factor that cho_factor keeps for small
+    systems): X L = 1 for the lower triangle of a well-conditioned factor, zeros above the
+    diagonal, nothing above the diagonal of L read (it holds NaN here); a padded row stride."""
+    import torch
+    from hydra_amd import _dev
+    rng = np.random.RandomState(n)
+    L = np.tril(rng.randn(n, n)) / np.sqrt(n) + np.diag(1.0 + rng.rand(n))
+    ld = n + 3
+    Ld = np.full((n, ld), np.nan)
+    Ld[:, :n] = np.where(np.tril(np.ones((n, n), dtype=bool)), L, np.nan)
+    Lg = torch.as_tensor(Ld, device="cuda")
+    X = torch.full((n, n), float("nan"), dtype=torch.float64, device="cuda")
+    _dev.call("hydra_tri_inverse", _dev.ptr(Lg), ld, n, _dev.ptr(X), n, _dev.stream_ptr())
+    Xh = X.cpu().numpy()
+    assert np.all(np.isfinite(Xh))
+    assert np.all(np.triu(Xh, 1) == 0.0)
+    assert np.max(np.abs(Xh @ L - np.eye(n))) <= 1e-12 * np.linalg.cond(L)
+    assert relerr(Xh, np.linalg.inv(L)) <= 1e-12 * np.linalg.cond(L)
+
+
 def test_apply_gains_matches_reference_golden(hy):
     g = load_golden("gains.npz")
     ap = _pairs(g["antpairs"])
