@@ -375,7 +375,10 @@ def test_cg_matches_reference_golden(hy, orc):
 def test_dense_fallback_matches_scipy(hy):
     import scipy.linalg
     rng = np.random.RandomState(2)
-    for n in (1, 31, 32, 33, 100, 257):
+    # (from 1024 unknowns on the sweeps run one launch per 256-wide panel -- even n only -- and
+    # the factorisation one launch per 32 columns: sizes on both sides of those edges, a last
+    # panel of 2 and of 254 entries, an odd size that keeps the one-workgroup sweeps)
+    for n in (1, 31, 32, 33, 100, 257, 1022, 1024, 1026, 1279, 1280, 1534, 2000, 2050):
         B = rng.randn(2 * n + 3, n)
         A = np.eye(n) + 0.1 * (B.T @ B)
         b = rng.randn(n)
