@@ -957,6 +957,57 @@ chol_bwd_step_kernel(const double* __restrict__ A, size_t ld, int n, int k, doub
   }
 }
 
+// y += A x for a symmetric operator of which only the STRICT UPPER triangle and the diagonal are
+// left -- after an in-place factorisation the lower triangle holds L -- for the rows a rank owns
+// (local row i = global row rows[i], ascending): first the rows (one wave per row: d_i x_i and the
+// entries right of the diagonal), then their mirror images (one thread per column j: the entries
+// above the diagonal of column j in this rank's rows).  The residual check of a kept factor.
+__global__ void __launch_bounds__(256)
+symv_upper_rows_kernel(const double* __restrict__ A, size_t ld, int nloc, int n,
+                       const long long* __restrict__ rows, const double* __restrict__ diag,
+                       const double* __restrict__ x, double* __restrict__ y) {
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  for (int i = blockIdx.x * 4 + wave; i < nloc; i += gridDim.x * 4) {
+    const int gi = (int)rows[i];
+    const double* row = A + (size_t)i * ld;
+    double s0 = 0.0, s1 = 0.0;
+    int j = gi + 1 + lane;
+    for (; j + 64 < n; j += 128) {
+      s0 += row[j] * x[j];
+      s1 += row[j + 64] * x[j + 64];
+    }
+    if (j < n) s0 += row[j] * x[j];
+    const double t = wave_sum(s0 + s1);
+    if (lane == 0) y[gi] += diag[i] * x[gi] + t;
+  }
+}
+__global__ void __launch_bounds__(256)
+symv_upper_cols_kernel(const double* __restrict__ A, size_t ld, int nloc, int n,
+                       const long long* __restrict__ rows, const double* __restrict__ x,
+                       double* __restrict__ y) {
+  const int j = blockIdx.x * 256 + threadIdx.x;
+  const int jc = min(j, n - 1);
+  const double* col = A + jc;
+  double s0 = 0.0, s1 = 0.0;
+  // rows with global index < the first column of this workgroup count for all of its threads;
+  // the few after that are tested one by one
+  const int j_first = blockIdx.x * 256;
+  int i = 0;
+  for (; i + 8 <= nloc && rows[i + 7] < j_first; i += 8) {
+    double v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(i + u) * ld];
+#pragma unroll
+    for (int u = 0; u < 8; u += 2) {
+      s0 += v[u] * x[rows[i + u]];
+      s1 += v[u + 1] * x[rows[i + u + 1]];
+    }
+  }
+  for (; i < nloc && rows[i] < j_first + 256; ++i)
+    if (rows[i] < j) s0 += col[(size_t)i * ld] * x[rows[i]];
+  if (j < n) y[j] += s0 + s1;
+}
+
 // X = L^-1, one workgroup per block column J of 32 columns: for the row blocks I = J, J+1, ...
 //   X[I,J] = L[I,I]^-1 ( [I == J] 1 - sum_{J <= K < I} L[I,K] X[K,J] ),
 // the 32 x 32 products by all 32 x 32 threads through LDS, the diagonal-block solve by 32 threads
@@ -1249,6 +1300,18 @@ int hydra_chol_apply(const double* L, double* b, int n, void* stream) {
   HYDRA_CHECK_ARG(L && b && n > 0, "hydra_chol_apply: bad arguments");
   hipStream_t s = as_stream(stream);
   return chol_solve_any(L, b, n, s);
+}
+
+int hydra_symv_upper(const double* A, long long ld, int nloc, int n, const long long* rows,
+                     const double* diag, const double* x, double* y, void* stream) {
+  HYDRA_CHECK_ARG(A && rows && diag && x && y && nloc >= 0 && n > 0 && ld >= n,
+                  "hydra_symv_upper: bad arguments (nloc=%d n=%d)", nloc, n);
+  if (nloc == 0) return HYDRA_OK;
+  hipStream_t s = as_stream(stream);
+  symv_upper_rows_kernel<<<std::min((nloc + 3) / 4, 8192), 256, 0, s>>>(A, (size_t)ld, nloc, n, rows, diag, x, y);
+  symv_upper_cols_kernel<<<(n + 255) / 256, 256, 0, s>>>(A, (size_t)ld, nloc, n, rows, x, y);
+  HYDRA_CHECK_LAUNCH("hydra_symv_upper");
+  return HYDRA_OK;
 }
 
 int hydra_tri_inverse(const double* L, long long ld, int n, double* X, long long ldx, void* stream) {

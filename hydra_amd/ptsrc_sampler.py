@@ -348,28 +348,28 @@ class SystemCache:
             return self.factor.solve(bvec)
         return linear_solver.cho_solve(self.factor, bvec)
 
-    def matvec(self, x, block=4096):
+    def matvec(self, x):
         """A x, whether or not ``solve`` has overwritten the lower triangle with the factor (then
-        from the strict upper triangle, its transpose and the saved diagonal, in row blocks)."""
-        xd = _dev.f64(x)
+        from the strict upper triangle, its mirror image and the saved diagonal:
+        ``hydra_symv_upper``).  The driver's residual check; every rank gets the whole product."""
+        xd = _dev.f64(x).contiguous()
         n = self.A.shape[1]
         y = torch.zeros(n, dtype=torch.float64, device=xd.device)
+        nloc = self.A.shape[0]
         if self.rows:
             lay = self.comm.row_layout(n)
-            blocks = [(lay.local_start(b),) + lay.block_range(b) for b in lay.blocks_of()]
             rows = self.comm._rows_dev(lay, lay.rank, xd.device)
         else:
-            blocks, rows = [(0, 0, n)], slice(0, n)
+            rows = torch.arange(n, dtype=torch.int64, device=xd.device)
         if self.factor is None or (not self.rows and self.factor.L is not self.A):
-            y[rows] = self.A @ xd
-        else:
-            y[rows] = self.diag * xd[rows]
-            for l0, g0, g1 in blocks:              # (first local row, global rows [g0, g1))
-                for i0 in range(g0, g1, block):
-                    i1 = min(i0 + block, g1)
-                    U = torch.triu(self.A[l0 + i0 - g0:l0 + i1 - g0], diagonal=i0 + 1)
-                    y[i0:i1] += U @ xd
-                    y += U.T @ xd[i0:i1]
+            if nloc:
+                part = torch.empty(nloc, dtype=torch.float64, device=xd.device)
+                _dev.call("hydra_gemv_rows", _dev.ptr(self.A), nloc, n, _dev.ptr(xd), _dev.ptr(part), 0,
+                          _dev.stream_ptr())
+                y[rows] = part
+        elif nloc:
+            _dev.call("hydra_symv_upper", _dev.ptr(self.A), n, nloc, n, _dev.ptr(rows.contiguous()),
+                      _dev.ptr(self.diag), _dev.ptr(xd), _dev.ptr(y), _dev.stream_ptr())
         if self.rows:
             self.comm.allreduce_(y)
         return y

@@ -382,6 +382,15 @@ int hydra_chol_apply(const double* L, double* b, int n, void* stream);
  * matrix, column block by column block, one workgroup per 32 columns.                      */
 int hydra_tri_inverse(const double* L, long long ld, int n, double* X, long long ldx, void* stream);
 
+/* y += A x for the symmetric operator of the source head (ptsrc_sampler.py:62-94) of which an
+ * in-place factorisation has left only the strict upper triangle (the lower one holds L) and the
+ * saved diagonal: the driver's residual check |A x - b| (example.py:974-976 style diagnostics) on a
+ * kept factor without a second copy of the matrix.  A (nloc, >= n) with row stride ld: the rows a
+ * rank owns, local row i = global row rows[i] (int64, ascending; all of 0..n-1 on one GPU);
+ * diag (nloc); x, y (n).  A rank adds its rows' part; the caller sums y over ranks.            */
+int hydra_symv_upper(const double* A, long long ld, int nloc, int n, const long long* rows,
+                     const double* diag, const double* x, double* y, void* stream);
+
 /* The large-matrix algorithm behind hydra_chol_solve (taken automatically for even n >= 6144):
  * 256-wide panels factored by 32-wide steps, then ONE rank-256 update of the rest of the lower
  * triangle per panel on the FP64 matrix cores (C -= P P^T, P = the finished panel read in place),
