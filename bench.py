@@ -56,6 +56,9 @@ CONFIGS = {
     "c5q": ((11, 21), 100000, 2, 1),
 }
 PER_GPU_CHANNELS = ("c5",)       # Nf above is per GPU: the job has Nf x n_gpus channels
+#: up to this many sources a multi-GPU job all-reduces the system and every rank solves it
+#: ("small N"); above it the root solves, or the operator stays sharded by rows
+REPLICATE_MAX_N = 20000
 SH_CONFIGS = {
     # spherical-harmonic head -- name: (hex_spec, lmax, nside, Nf, Nt)
     # c3 = BASELINE config 3 (HERA-127, lmax 40, 128 freqs); Nt is left open by BASELINE.json and
@@ -1023,7 +1026,7 @@ def self_launch(ngpus):
     """``python bench.py --gpus N`` without torchrun's environment: run the same command line
     under ``python -m torch.distributed.run`` (one rank per GPU, rendezvous on 127.0.0.1 at a free
     port) as a CHILD process -- this process has made no GPU call and makes none -- and exit with
-    the child's status.  Rank 0's JSON line arrives on the inherited stdout."""
+    the child's status.  Rank 0's JSON line is passed on alone."""
     import socket
     import subprocess
     with socket.socket() as s:
@@ -1036,9 +1039,21 @@ def self_launch(ngpus):
            f"--nproc-per-node={ngpus}", "--master-addr", "127.0.0.1", "--master-port", str(port),
            os.path.abspath(__file__)] + sys.argv[1:]
     sys.stdout.flush()
-    rc = subprocess.run(cmd, env=env).returncode
-    if rc != 0:
-        sys.exit(rc)
+    # stdout of this command is ONE JSON line: pass rank 0's line on and send whatever else the
+    # ranks or their libraries write there (gloo reports its connections on stdout) to stderr
+    done = subprocess.run(cmd, env=env, stdout=subprocess.PIPE, text=True)
+    lines = [ln for ln in done.stdout.splitlines() if ln.strip()]
+    result = [ln for ln in lines if ln.lstrip().startswith('{"metric"')]
+    for ln in lines:
+        if ln not in result:
+            print(ln, file=sys.stderr)
+    if result:
+        print(result[-1])
+    sys.stdout.flush()
+    if done.returncode != 0:
+        sys.exit(done.returncode)
+    if not result:
+        sys.exit("bench.py: the ranks printed no result line")
 
 
 def main():
@@ -1192,12 +1207,17 @@ def main():
             ev[1].record()
             solve_events.append(ev)
             return keep, b, x, 0
+        # small systems over several GPUs: the sums are all-reduces, every rank holds
+        # the whole system and solves it for itself -- no broadcast of x, no rank waits for the root
+        replicated = comm is not None and ns <= REPLICATE_MAX_N
         A, b = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
-                                            inv_noise, gains, prior, omega_n=om_n, omega_a=om_a)
-        if rank == 0 and args.solver == "cg":
+                                            inv_noise, gains, prior, omega_n=om_n, omega_a=om_a,
+                                            replicate=replicated)
+        solver_here = rank == 0 or replicated
+        if solver_here and args.solver == "cg":
             x, iters = hy.linear_solver.cg(A, b, maxiters=1000, abs_tol=args.cg_tol,
                                            return_iters=True)
-        elif rank == 0:
+        elif solver_here:
             # A is rebuilt every sample, so the factorisation may overwrite it (no 80 GB copy);
             # keep what the residual check below needs
             ev = (torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True))
@@ -1212,7 +1232,7 @@ def main():
                 A = None
         else:
             x, iters = torch.zeros(ns, dtype=torch.float64, device=dev), 0
-        if comm is not None:
+        if comm is not None and not replicated:
             comm.bcast_(x, root=0)
         return A, b, x, iters
 
@@ -1257,14 +1277,16 @@ def main():
         def fixed_sample():
             om_n = torch.randn((nbl, nf_loc, nt), dtype=torch.complex128, device=dev, generator=gen)
             om_a = torch.randn(ns, dtype=torch.float64, device=dev, generator=gen)
+            repl = comm is not None and not rows_mode and ns <= REPLICATE_MAX_N
             _, b_c = ptsrc_sampler.precompute_mpi(comm, ants, antpairs, freqs_loc, times, fac, data,
                                                   inv_noise, gains, prior, omega_n=om_n,
-                                                  omega_a=om_a, shard_rows=rows_mode, cache=cache)
-            if rows_mode or rank == 0:
+                                                  omega_a=om_a, shard_rows=rows_mode, cache=cache,
+                                                  replicate=repl)
+            if rows_mode or repl or rank == 0:
                 x_c = cache.solve(b_c)
             else:
                 x_c = torch.zeros(ns, dtype=torch.float64, device=dev)
-            if comm is not None and not rows_mode:
+            if comm is not None and not rows_mode and not repl:
                 comm.bcast_(x_c, root=0)
             return b_c, x_c
 
@@ -1388,6 +1410,10 @@ def main():
             "flagged_fraction": args.flags,
             "flagged_rows_corrected": int(getattr(fac, "last_gram_flagged_rows", 0)),
             "parallelism": f"{shard}-sharded x{world}" if world > 1 else "single GPU",
+            "solve_placement": ("one GPU" if world == 1 else
+                                "operator sharded by rows over the GPUs" if args.solver in ("cg-rows", "dense-rows") else
+                                "system all-reduced, solved on every GPU (no broadcast)" if ns <= REPLICATE_MAX_N else
+                                "root solves, solution broadcast"),
         },
         # the metric's "Gram FP64 TFLOP/s" as an EFFECTIVE rate: baseline-form flops 2 M Ns (Ns+1)
         # over the Gram time, whole job.  Not a roofline figure: it exceeds the matrix peak when

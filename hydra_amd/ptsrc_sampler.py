@@ -411,7 +411,7 @@ def _draw_omega_n(shape, realisation):
 
 def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, data_chunk,
                    inv_noise_var_chunk, gain_chunk, amp_prior_std, realisation=True,
-                   omega_n=None, omega_a=None, shard_rows=False, cache=None):
+                   omega_n=None, omega_a=None, shard_rows=False, cache=None, replicate=False):
     """Linear operator and right-hand side of the point-source GCR system
     (ptsrc_sampler.py:17-140).  With ``comm`` (``hydra_amd._dist.Comm``) every rank passes its
     (freq, time) chunk and the partial Gram / RHS are summed over ranks; only the root's
@@ -422,6 +422,12 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
     ``_dist.RowLayout``) and the full ``b``; solve with ``linear_solver.solve_dense_rows`` or
     ``linear_solver.cg(None, b, linear_op=linear_solver.RowShardedOperator(comm, A_rows, Ns))``.
     For source counts whose matrix one GPU holds but should not multiply alone (config 5).
+
+    ``replicate=True`` (with ``comm``; SURVEY 8(e), small systems): the sums are all-reduces and
+    EVERY rank returns the full system, bit for bit the same, so that each solves it for itself and
+    no broadcast of the solution follows (``cg(comm=...)`` of the reference also leaves x on every
+    rank, linear_solver.py:506-508).  The root's omega_a joins its partial right-hand side before
+    the sum.
 
     ``cache`` (a ``SystemCache``): keep the operator between calls and rebuild it only when the
     gains, the noise weights or the prior have changed; the returned ``A`` is then the cache's
@@ -498,6 +504,8 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         if omega_a is None:
             omega_a = (1.0 if realisation else 0.0) * np.random.randn(ns)
         om_a = _dev.f64(omega_a)
+    assert not (replicate and shard_rows), "replicate and shard_rows exclude each other"
+    replicate = bool(replicate and comm is not None)
     add_here = om_a if comm is None else None
     if factored:
         b = proj_chunk.adjoint(z, scale=sigma, add=add_here)
@@ -521,6 +529,15 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
         oa = om_a if myid == 0 else torch.zeros(ns, dtype=torch.float64, device=b.device)
         comm.bcast_(oa, root=0)
         b += oa
+    elif replicate:
+        # the same sums as all-reduces: the full system on every rank (the packed lower triangle on
+        # the wire, mirrored on arrival; omega_a rides in the root's term of b)
+        if myid == 0:
+            b += om_a
+        if not hit:
+            comm.allreduce_sym_(A)
+            _dev.call("hydra_prior_epilogue", _dev.ptr(A), ns, _dev.ptr(sigma), _dev.ptr(None), st)
+        comm.allreduce_(b)
     elif comm is not None:
         # sum over ranks (comm.Reduce at ptsrc_sampler.py:86,132), then prior + omega_a on root
         if not hit:
@@ -539,7 +556,7 @@ def precompute_mpi(comm, ants, antpairs, freq_chunk, time_chunk, proj_chunk, dat
             if cache.A is not None:
                 A = cache.A
         else:
-            keep_A = shard_rows or myid == 0
+            keep_A = shard_rows or replicate or myid == 0
             cache._store(comm, proj_chunk, gains, w, sigma, shard_rows, A, gg, model, keep_A)
     if (_dev.is_torch(ref) and not shard_rows and A.shape[0] == A.shape[1]
             and not (cache is not None and cache.factored)):

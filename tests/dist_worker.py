@@ -175,6 +175,21 @@ def case_ptsrc(comm):
                                     maxiters=1, comm=comm)
         x_ref = np.linalg.solve(A1, b1)
         assert np.max(np.abs(x - x_ref)) / np.max(np.abs(x_ref)) < 1e-8   # every rank holds x
+        # replicate=True (small systems): all-reduces, the whole system on EVERY rank,
+        # the same bits everywhere, so each rank solves for itself and nothing is broadcast
+        A3, b3 = hy.ptsrc_sampler.precompute_mpi(
+            comm, p["ants"], p["antpairs"], p["freqs"][fidx], p["times"], mine,
+            p["data"][:, fidx], p["inv_noise"][:, fidx], p["gains"][:, fidx], p["prior"],
+            omega_n=p["om_n"][:, fidx], omega_a=p["om_a"], replicate=True)
+        assert np.max(np.abs(A3 - A1)) / np.max(np.abs(A1)) < 1e-12
+        assert np.max(np.abs(b3 - b1)) / np.max(np.abs(b1)) < 1e-12
+        assert np.array_equal(A3, A3.T)
+        for arr in (A3, b3):
+            t = torch.as_tensor(np.ascontiguousarray(arr), device="cuda")
+            parts = comm.allgather(t)
+            assert all(torch.equal(q, parts[0]) for q in parts)
+        x3 = hy.linear_solver.solve_dense(A3, b3)
+        assert np.max(np.abs(x3 - x_ref)) / np.max(np.abs(x_ref)) < 1e-10
     comm.barrier()
 
 

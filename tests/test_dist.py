@@ -140,8 +140,8 @@ def _bench(extra, env_extra=None, timeout=300):
     res = subprocess.run([sys.executable, os.path.join(os.path.dirname(HERE), "bench.py")] + extra,
                          env=env, capture_output=True, text=True, timeout=timeout)
     assert res.returncode == 0, res.stdout[-1500:] + "\n" + res.stderr[-3000:]
-    lines = [ln for ln in res.stdout.splitlines() if ln.startswith("{")]
-    assert len(lines) == 1, res.stdout[-2000:]
+    lines = [ln for ln in res.stdout.splitlines() if ln.strip()]
+    assert len(lines) == 1 and lines[0].startswith("{"), res.stdout[-2000:]   # stdout: ONE JSON line
     return json.loads(lines[0])
 
 
