@@ -968,7 +968,7 @@ symv_upper_rows_kernel(const double* __restrict__ A, size_t ld, int nloc, int n,
                        const double* __restrict__ x, double* __restrict__ y) {
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   for (int i = blockIdx.x * 4 + wave; i < nloc; i += gridDim.x * 4) {
-    const int gi = (int)rows[i];
+    const int gi = (int)min(max(rows[i], 0LL), (long long)n - 1);   // (a bad index must not fault)
     const double* row = A + (size_t)i * ld;
     double s0 = 0.0, s1 = 0.0;
     int j = gi + 1 + lane;
@@ -999,12 +999,12 @@ symv_upper_cols_kernel(const double* __restrict__ A, size_t ld, int nloc, int n,
     for (int u = 0; u < 8; ++u) v[u] = col[(size_t)(i + u) * ld];
 #pragma unroll
     for (int u = 0; u < 8; u += 2) {
-      s0 += v[u] * x[rows[i + u]];
-      s1 += v[u + 1] * x[rows[i + u + 1]];
+      s0 += v[u] * x[max(rows[i + u], 0LL)];                 // (< j_first <= n here)
+      s1 += v[u + 1] * x[max(rows[i + u + 1], 0LL)];
     }
   }
   for (; i < nloc && rows[i] < j_first + 256; ++i)
-    if (rows[i] < j) s0 += col[(size_t)i * ld] * x[rows[i]];
+    if (rows[i] < j) s0 += col[(size_t)i * ld] * x[max(rows[i], 0LL)];
   if (j < n) y[j] += s0 + s1;
 }
 

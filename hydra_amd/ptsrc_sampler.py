@@ -368,7 +368,8 @@ class SystemCache:
                           _dev.stream_ptr())
                 y[rows] = part
         elif nloc:
-            _dev.call("hydra_symv_upper", _dev.ptr(self.A), n, nloc, n, _dev.ptr(rows.contiguous()),
+            rows = rows.contiguous()
+            _dev.call("hydra_symv_upper", _dev.ptr(self.A), n, nloc, n, _dev.ptr(rows),
                       _dev.ptr(self.diag), _dev.ptr(xd), _dev.ptr(y), _dev.stream_ptr())
         if self.rows:
             self.comm.allreduce_(y)

@@ -543,6 +543,39 @@ def test_triangular_inverse_kernel(hy, n):
     assert relerr(Xh, np.linalg.inv(L)) <= 1e-12 * np.linalg.cond(L)
 
 
+@pytest.mark.parametrize("n,size", [(1, 1), (7, 1), (300, 1), (1000, 3), (2306, 2)])
+def test_symmetric_product_from_the_upper_triangle(hy, n, size):
+    """hydra_symv_upper (SystemCache.matvec after an in-place factorisation): A x from the strict
+    upper triangle and the saved diagonal, for all rows and for the block-cyclic rows of each of
+    ``size`` ranks (summed here); what lies on and below the diagonal is NaN and must not be read."""
+    import torch
+    from hydra_amd import _dev, _dist
+    rng = np.random.RandomState(n)
+    M = rng.randn(n, n)
+    A = M + M.T
+    x = rng.randn(n)
+    want = A @ x
+    upper = np.where(np.triu(np.ones((n, n), dtype=bool), 1), A, np.nan)
+    total = np.zeros(n)
+    for r in range(size):
+        rows = _dist.RowLayout(n, size, r, block=256).rows()
+        if rows.size == 0:
+            continue
+        # (named tensors: a temporary handed to _dev.ptr() is freed, and its block reused by the
+        # next allocation, before the kernel runs)
+        Ad = torch.as_tensor(upper[rows], device="cuda").contiguous()
+        rows_d = torch.as_tensor(rows, dtype=torch.int64, device="cuda")
+        diag_d = torch.as_tensor(np.diag(A)[rows].copy(), device="cuda")
+        x_d = torch.as_tensor(x, device="cuda")
+        y = torch.zeros(n, dtype=torch.float64, device="cuda")
+        _dev.call("hydra_symv_upper", _dev.ptr(Ad), n, rows.size, n, _dev.ptr(rows_d),
+                  _dev.ptr(diag_d), _dev.ptr(x_d), _dev.ptr(y), _dev.stream_ptr())
+        torch.cuda.synchronize()
+        total += y.cpu().numpy()
+    assert np.all(np.isfinite(total))
+    assert relerr(total, want) < 1e-13
+
+
 def test_apply_gains_matches_reference_golden(hy):
     g = load_golden("gains.npz")
     ap = _pairs(g["antpairs"])
